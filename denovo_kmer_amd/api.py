@@ -1,0 +1,367 @@
+"""Host-side mirror of the reference's k-mer API over the C ABI.
+
+The reference (jlanej/denovo_kmer) exposes `KmerCounter` and `KmerSet` from counter.rs and the
+extraction helpers from kmer.rs (both NOT IN MOUNT -- SURVEY.md 0.1); the classes here keep those
+names and the argument meaning BASELINE.json describes (k, sequences in, k-mer -> count out,
+set membership), and delegate every computation to libdenovo_kmer.so.  Nothing here computes
+k-mers on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DkConfig, DkStats, DkSynthConfig, DkTimings, check
+
+# kernel families smoke() and the GPU tests sweep ("bucketed" joins once its kernels land)
+SMOKE_MODES = ("direct",)
+
+_CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+_BASE = "ACGT"
+
+
+def kmer_from_str(s):
+    """'ACGT' -> (hi, lo) under spec A-1 (first base most significant).  Host utility only."""
+    v = 0
+    for ch in s.upper():
+        v = (v << 2) | _CODE[ch]
+    return v >> 64, v & (2**64 - 1)
+
+
+def kmer_to_str(hi, lo, k):
+    v = (int(hi) << 64) | int(lo)
+    return "".join(_BASE[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def _concat(reads):
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offsets[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    seq = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return seq, offsets
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Engine:
+    """One GPU + one stream + the k-mer / filter geometry (dk_engine)."""
+
+    def __init__(self, k=31, canonical=True, filter_log2_bits=30, n_hashes=4, seed=0x5EED,
+                 min_count=1, device_id=0, mode="auto", rank=0, world_size=1, stream=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        mode_id = {"auto": _lib.MODE_AUTO, "direct": _lib.MODE_DIRECT, "bucketed": _lib.MODE_BUCKETED}[mode]
+        cfg = DkConfig(C.sizeof(DkConfig), k, int(bool(canonical)), filter_log2_bits, n_hashes,
+                       seed & (2**64 - 1), min_count, device_id, rank, world_size, mode_id, stream)
+        check(self._lib.dk_engine_create(C.byref(cfg), C.byref(self._h)))
+        self.k = k
+        self.canonical = bool(canonical)
+        self.filter_log2_bits = filter_log2_bits
+        self.n_hashes = n_hashes
+        self.seed = seed & (2**64 - 1)
+        self.min_count = min_count
+        self.device_id = device_id
+        self.mode = mode
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("engine is closed")
+        return self._h
+
+    def check(self, status):
+        check(status, self._h)
+
+    def synchronize(self):
+        self.check(self._lib.dk_engine_synchronize(self.handle))
+
+    def timings(self):
+        t = DkTimings()
+        self.check(self._lib.dk_engine_timings(self.handle, C.byref(t)))
+        return t.as_dict()
+
+    def or_reduce_slices(self, dst_ptr, src_ptr, n_slices, slice_bytes):
+        """dst |= OR of n_slices slices at src (device pointers): local step of the OR-all-reduce."""
+        self.check(self._lib.dk_or_reduce_slices(self.handle, C.c_void_p(dst_ptr), C.c_void_p(src_ptr),
+                                                 n_slices, slice_bytes))
+
+    def close(self):
+        if self._h:
+            self._lib.dk_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_config(seed=20260313, genome_len=50_000, read_len=150, snv_rate=1e-3, denovo_rate=None,
+                 err_rate=5e-3, n_rate=1e-4, xover_log2=20):
+    """Synthetic-trio parameters; rates become 64-bit thresholds."""
+    if denovo_rate is None:
+        denovo_rate = 100.0 / (64 << 20)
+
+    def thr(rate):
+        return 0 if rate <= 0 else (2**64 - 1 if rate >= 1 else int(rate * 2.0**64))
+
+    return DkSynthConfig(C.sizeof(DkSynthConfig), seed, genome_len, read_len, xover_log2,
+                         thr(snv_rate), thr(denovo_rate), thr(err_rate), thr(n_rate))
+
+
+class ReadBatch:
+    """A device-resident packed read batch (dk_reads)."""
+
+    def __init__(self, engine, handle, keepalive=None):
+        self.engine = engine
+        self._h = handle
+        self._keep = keepalive
+
+    @classmethod
+    def from_sequences(cls, engine, reads):
+        seq, offsets = _concat(reads)
+        return cls.from_ascii(engine, seq, offsets)
+
+    @classmethod
+    def from_ascii(cls, engine, seq, offsets):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        engine.check(engine._lib.dk_reads_from_ascii(engine.handle, _vp(seq), _vp(offsets),
+                                                     len(offsets) - 1, C.byref(h)))
+        return cls(engine, h)
+
+    @classmethod
+    def from_packed(cls, engine, bases, mask, n_bases, n_reads, n_windows):
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        mask = np.ascontiguousarray(mask, dtype=np.uint64)
+        assert bases.size >= (n_bases + 31) // 32 and mask.size >= (n_bases + 63) // 64
+        h = C.c_void_p()
+        engine.check(engine._lib.dk_reads_from_packed(engine.handle, _vp(bases), _vp(mask), n_bases,
+                                                      n_reads, n_windows, C.byref(h)))
+        return cls(engine, h)
+
+    @classmethod
+    def attach_device(cls, engine, d_bases, d_mask, n_bases, n_reads, n_windows, keepalive=None):
+        h = C.c_void_p()
+        engine.check(engine._lib.dk_reads_attach_device(engine.handle, C.c_void_p(d_bases), C.c_void_p(d_mask),
+                                                        n_bases, n_reads, n_windows, C.byref(h)))
+        return cls(engine, h, keepalive)
+
+    @classmethod
+    def synth(cls, engine, cfg, sample, first_read, n_reads):
+        h = C.c_void_p()
+        engine.check(engine._lib.dk_reads_synth(engine.handle, C.byref(cfg), sample, first_read, n_reads, C.byref(h)))
+        return cls(engine, h)
+
+    def stats(self):
+        st = DkStats()
+        self.engine.check(self.engine._lib.dk_reads_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def download(self):
+        n = self.stats()["n_bases"]
+        bases = np.zeros((n + 31) // 32, dtype=np.uint64)
+        mask = np.zeros((n + 63) // 64, dtype=np.uint64)
+        self.engine.check(self.engine._lib.dk_reads_download(self._h, _vp(bases), _vp(mask)))
+        return bases, mask, n
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                self.engine._lib.dk_reads_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_ascii_host(seq, offsets):
+    """CPU packer of the C ABI (dk_pack_ascii_host): for hosts that pack while reading BAM."""
+    lib = _lib.load()
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n_reads = len(offsets) - 1
+    total = int(offsets[-1]) + n_reads if n_reads else 0
+    bases = np.zeros((total + 31) // 32 + 1, dtype=np.uint64)
+    mask = np.zeros((total + 63) // 64 + 1, dtype=np.uint64)
+    t = lib.dk_pack_ascii_host(_vp(seq), _vp(offsets), n_reads, _vp(bases), _vp(mask))
+    assert t == total
+    return bases[: (total + 31) // 32], mask[: (total + 63) // 64], total
+
+
+class KmerCounts:
+    """k-mer -> count table returned by the GPU (dk_result).  Unordered, like a HashMap."""
+
+    def __init__(self, engine, handle, stats):
+        self.engine = engine
+        self._h = handle
+        self.stats = stats
+        self._host = None
+
+    def __len__(self):
+        n = C.c_uint64()
+        self.engine.check(self.engine._lib.dk_result_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def to_host(self, sort=True):
+        """-> (hi, lo, counts) numpy arrays; sorted by (hi, lo) when sort=True."""
+        if self._host is None:
+            n = len(self)
+            lo = np.zeros(n, dtype=np.uint64)
+            hi = np.zeros(n, dtype=np.uint64)
+            cnt = np.zeros(n, dtype=np.uint32)
+            if n:
+                self.engine.check(self.engine._lib.dk_result_copy(self._h, _vp(lo), _vp(hi), _vp(cnt)))
+            self._host = (hi, lo, cnt)
+        hi, lo, cnt = self._host
+        if sort and len(lo):
+            order = np.lexsort((lo, hi))
+            return hi[order], lo[order], cnt[order]
+        return hi, lo, cnt
+
+    def device_view(self):
+        plo, phi, pc, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self.engine.check(self.engine._lib.dk_result_device_view(self._h, C.byref(plo), C.byref(phi), C.byref(pc), C.byref(n)))
+        return plo.value, phi.value, pc.value, int(n.value)
+
+    def as_dict(self):
+        hi, lo, cnt = self.to_host(sort=False)
+        k = self.engine.k
+        return {kmer_to_str(h, l, k): int(c) for h, l, c in zip(hi, lo, cnt)}
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                self.engine._lib.dk_result_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KmerSet:
+    """Parent k-mer set: a blocked Bloom filter resident in HBM (dk_set).
+
+    Mirrors counter.rs `KmerSet` (insert / contains); membership has Bloom semantics: no false
+    negatives, false positives at the filter's rate."""
+
+    def __init__(self, engine, device_ptr=None, keepalive=None):
+        self.engine = engine
+        self._h = C.c_void_p()
+        self._keep = keepalive
+        if device_ptr is None:
+            engine.check(engine._lib.dk_set_create(engine.handle, C.byref(self._h)))
+        else:
+            engine.check(engine._lib.dk_set_attach(engine.handle, C.c_void_p(device_ptr), C.byref(self._h)))
+        self.n_bytes = (1 << engine.filter_log2_bits) // 8
+        self.last_stats = None
+
+    def insert_reads(self, batch):
+        st = DkStats()
+        self.engine.check(self.engine._lib.dk_set_insert(self._h, batch._h, C.byref(st)))
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
+    def insert_sequences(self, reads):
+        b = ReadBatch.from_sequences(self.engine, reads)
+        try:
+            return self.insert_reads(b)
+        finally:
+            b.close()
+
+    def contains(self, kmers):
+        """kmers: iterable of str, or (hi, lo) uint64 arrays.  -> bool array"""
+        if isinstance(kmers, tuple):
+            hi = np.ascontiguousarray(kmers[0], dtype=np.uint64)
+            lo = np.ascontiguousarray(kmers[1], dtype=np.uint64)
+        else:
+            pairs = [kmer_from_str(s) for s in kmers]
+            hi = np.array([p[0] for p in pairs], dtype=np.uint64)
+            lo = np.array([p[1] for p in pairs], dtype=np.uint64)
+        out = np.zeros(len(lo), dtype=np.uint8)
+        self.engine.check(self.engine._lib.dk_set_contains(self._h, _vp(lo), _vp(hi) if self.engine.k > 32 else None,
+                                                           len(lo), _vp(out)))
+        return out.astype(bool)
+
+    def clear(self):
+        self.engine.check(self.engine._lib.dk_set_clear(self._h))
+
+    def popcount(self):
+        n = C.c_uint64()
+        self.engine.check(self.engine._lib.dk_set_popcount(self._h, C.byref(n)))
+        return int(n.value)
+
+    @property
+    def device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self.engine.check(self.engine._lib.dk_set_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value
+
+    def to_host(self):
+        words = np.zeros(self.n_bytes // 8, dtype=np.uint64)
+        self.engine.check(self.engine._lib.dk_set_download(self._h, _vp(words)))
+        return words
+
+    def from_host(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        assert words.size == self.n_bytes // 8
+        self.engine.check(self.engine._lib.dk_set_upload(self._h, _vp(words)))
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                self.engine._lib.dk_set_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KmerCounter:
+    """Mirrors counter.rs `KmerCounter`: per-k-mer occurrence counts of a sample, and the
+    child-only ("de-novo") pass against a parent `KmerSet`."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def _probe(self, kset, batch):
+        h = C.c_void_p()
+        st = DkStats()
+        e = self.engine
+        e.check(e._lib.dk_probe(e.handle, kset._h if kset is not None else None, batch._h, C.byref(h), C.byref(st)))
+        return KmerCounts(e, h, st.as_dict())
+
+    def count_reads(self, batch):
+        """all canonical k-mers of the batch with their counts"""
+        return self._probe(None, batch)
+
+    def count_sequences(self, reads):
+        b = ReadBatch.from_sequences(self.engine, reads)
+        try:
+            return self.count_reads(b)
+        finally:
+            b.close()
+
+    def child_only(self, batch, parents):
+        """k-mers of the (child) batch absent from the parent set, with their child counts"""
+        return self._probe(parents, batch)

@@ -1,0 +1,825 @@
+// dk_api.hip -- C ABI of libdenovo_kmer.so (include/denovo_kmer.h): handle management, stream
+// and workspace plumbing, kernel launches.  No CPU fallback exists: without a HIP device every
+// entry point that needs one fails with DK_ERR_NO_DEVICE.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "dk_internal.h"
+#include "dk_kernels_bucket.h"
+
+static thread_local std::string g_create_err;
+
+namespace dk {
+
+dk_status fail(dk_engine *e, dk_status s, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_err = buf;
+    return s;
+}
+
+// ---- caching device allocator (grow-only; blocks are reused across operations) ---------------
+dk_status pool_alloc(dk_engine *e, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < e->pool.size(); i++) {
+        dk_pool_block &b = e->pool[i];
+        if (b.in_use || b.bytes < bytes || b.bytes > 2 * bytes + (1 << 20)) continue;
+        if (best < 0 || b.bytes < e->pool[best].bytes) best = (int)i;
+    }
+    if (best >= 0) {
+        e->pool[best].in_use = true;
+        *out = e->pool[best].ptr;
+        return DK_OK;
+    }
+    void *p = nullptr;
+    hipError_t r = hipMalloc(&p, bytes);
+    if (r != hipSuccess) {
+        // release every cached free block and retry once
+        for (auto &b : e->pool)
+            if (!b.in_use && b.ptr) { (void)hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
+        e->pool.erase(std::remove_if(e->pool.begin(), e->pool.end(),
+                                     [](const dk_pool_block &b) { return b.ptr == nullptr; }),
+                      e->pool.end());
+        r = hipMalloc(&p, bytes);
+        if (r != hipSuccess)
+            return fail(e, DK_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+    }
+    e->pool.push_back({p, bytes, true});
+    *out = p;
+    return DK_OK;
+}
+
+void pool_free(dk_engine *e, void *p)
+{
+    if (!p) return;
+    for (auto &b : e->pool)
+        if (b.ptr == p) { b.in_use = false; return; }
+}
+
+void stage_begin(dk_engine *e)
+{
+    e->n_ev = 0;
+    (void)hipEventRecord(e->ev[0], e->stream);
+}
+
+void stage_mark(dk_engine *e, const char *name)
+{
+    if (e->n_ev >= DK_MAX_STAGES) return;
+    snprintf(e->ev_name[e->n_ev], sizeof e->ev_name[0], "%s", name);
+    e->n_ev++;
+    (void)hipEventRecord(e->ev[e->n_ev], e->stream);
+}
+
+dk_status stage_end(dk_engine *e)
+{
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    dk_timings &t = e->timings;
+    memset(&t, 0, sizeof t);
+    t.n_stages = (uint32_t)e->n_ev;
+    for (int i = 0; i < e->n_ev; i++) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
+        t.stage_ms[i] = ms;
+        memcpy(t.stage_name[i], e->ev_name[i], sizeof t.stage_name[i]);
+    }
+    if (e->n_ev) (void)hipEventElapsedTime(&t.total_ms, e->ev[0], e->ev[e->n_ev]);
+    return DK_OK;
+}
+
+int grid_for(const dk_engine *e, uint64_t n_threads, int block)
+{
+    uint64_t blocks = (n_threads + block - 1) / block;
+    const uint64_t cap = (uint64_t)e->n_cu * 8;     // 8 blocks of 256 per CU fill every wave slot
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static dk_status read_counters(dk_engine *e)
+{
+    DK_HIP(e, hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+static StreamView view_of(const dk_reads *r)
+{
+    StreamView s;
+    s.bases = r->d_bases;
+    s.mask = r->d_mask;
+    s.n_bases = r->n_bases;
+    s.n_bwords = (r->n_bases + 31) / 32;
+    s.n_mwords = (r->n_bases + 63) / 64;
+    return s;
+}
+
+static FilterView fview_of(const dk_engine *e, const dk_set *s)
+{
+    FilterView f;
+    f.words = s ? s->d_words : nullptr;
+    f.log2_blocks = (int)e->cfg.filter_log2_bits - 9;
+    f.n_hashes = (int)e->cfg.n_hashes;
+    f.seed = e->cfg.seed;
+    return f;
+}
+
+}  // namespace dk
+
+using namespace dk;
+
+static int ceil_log2(uint64_t v)
+{
+    int l = 0;
+    while ((1ULL << l) < v) l++;
+    return l;
+}
+
+template <bool WIDE>
+static dk_status probe_direct(dk_engine *e, dk_set *s, const dk_reads *r, dk_result *res)
+{
+    const StreamView sv = view_of(r);
+    const FilterView fv = fview_of(e, s);
+    uint64_t cand_cap = std::min(r->n_bases, r->n_windows ? r->n_windows : r->n_bases);
+    if (cand_cap == 0) cand_cap = 1;
+    uint64_t *cand_lo = nullptr, *cand_hi = nullptr;
+    uint32_t *slots = nullptr, *counts = nullptr;
+    dk_status st = pool_alloc(e, cand_cap * 8, (void **)&cand_lo);
+    if (st == DK_OK && WIDE) st = pool_alloc(e, cand_cap * 8, (void **)&cand_hi);
+    auto cleanup = [&]() {
+        pool_free(e, cand_lo);
+        pool_free(e, cand_hi);
+        pool_free(e, slots);
+        pool_free(e, counts);
+    };
+    if (st != DK_OK) { cleanup(); return st; }
+
+    probe_direct_kernel<WIDE><<<grid_for(e, r->n_bases, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+        sv, fv, (int)e->cfg.k, (int)e->cfg.canonical, e->d_ctr, cand_lo, cand_hi, cand_cap);
+    hipError_t h = hipGetLastError();
+    if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "probe_direct launch failed: %s", hipGetErrorString(h)); }
+    stage_mark(e, "probe_direct");
+    st = read_counters(e);
+    if (st != DK_OK) { cleanup(); return st; }
+    const uint64_t n_cand = e->h_ctr->n_cand;
+    if (n_cand > cand_cap) { cleanup(); return fail(e, DK_ERR_OVERFLOW, "candidate list overflow (%llu > %llu): n_windows under-stated?", (unsigned long long)n_cand, (unsigned long long)cand_cap); }
+    if (n_cand >= 0xFFFFFFFFULL) { cleanup(); return fail(e, DK_ERR_OVERFLOW, "more than 2^32-1 absent k-mers in one batch; split the batch"); }
+    if (n_cand == 0) { cleanup(); return DK_OK; }
+
+    const int log2_cap = std::max(10, ceil_log2(2 * n_cand));
+    const uint64_t cap = 1ULL << log2_cap;
+    st = pool_alloc(e, cap * 4, (void **)&slots);
+    if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&counts);
+    if (st == DK_OK) st = pool_alloc(e, n_cand * 8, (void **)&res->d_lo);
+    if (st == DK_OK && WIDE) st = pool_alloc(e, n_cand * 8, (void **)&res->d_hi);
+    if (st == DK_OK) st = pool_alloc(e, n_cand * 4, (void **)&res->d_cnt);
+    if (st != DK_OK) { cleanup(); return st; }
+    h = hipMemsetAsync(slots, 0xFF, cap * 4, e->stream);
+    if (h == hipSuccess) h = hipMemsetAsync(counts, 0, cap * 4, e->stream);
+    if (h == hipSuccess) {
+        count_insert_kernel<WIDE><<<grid_for(e, n_cand, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            cand_lo, cand_hi, n_cand, slots, counts, log2_cap, e->cfg.seed);
+        h = hipGetLastError();
+    }
+    if (h == hipSuccess) {
+        stage_mark(e, "count_insert");
+        count_emit_kernel<WIDE><<<grid_for(e, cap, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            cand_lo, cand_hi, slots, counts, cap, e->cfg.min_count, e->d_ctr, res->d_lo, res->d_hi, res->d_cnt);
+        h = hipGetLastError();
+    }
+    if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "count kernels failed: %s", hipGetErrorString(h)); }
+    stage_mark(e, "count_emit");
+    st = read_counters(e);
+    cleanup();
+    if (st != DK_OK) return st;
+    res->n = e->h_ctr->n_emitted;
+    return DK_OK;
+}
+
+#define CHECK_ARG(e, cond)                                                              \
+    do {                                                                                \
+        if (!(cond)) return dk::fail((e), DK_ERR_INVALID_ARG, "invalid argument: %s", #cond); \
+    } while (0)
+
+extern "C" {
+
+int32_t dk_abi_version(void) { return DK_ABI_VERSION; }
+
+const char *dk_status_string(dk_status s)
+{
+    switch (s) {
+    case DK_OK: return "ok";
+    case DK_ERR_INVALID_ARG: return "invalid argument";
+    case DK_ERR_NO_DEVICE: return "no HIP device";
+    case DK_ERR_HIP: return "HIP runtime error";
+    case DK_ERR_OOM: return "out of device memory";
+    case DK_ERR_UNSUPPORTED: return "unsupported configuration";
+    case DK_ERR_OVERFLOW: return "capacity overflow";
+    default: return "unknown status";
+    }
+}
+
+// ---- engine ------------------------------------------------------------------------------------
+dk_status dk_engine_create(const dk_config *cfg, dk_engine **out)
+{
+    if (!cfg || !out) return fail(nullptr, DK_ERR_INVALID_ARG, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(dk_config))
+        return fail(nullptr, DK_ERR_INVALID_ARG, "dk_config.struct_size %llu != %zu",
+                    (unsigned long long)cfg->struct_size, sizeof(dk_config));
+    if (cfg->k < 1 || cfg->k > 64) return fail(nullptr, DK_ERR_INVALID_ARG, "k=%u outside 1..64", cfg->k);
+    if (cfg->filter_log2_bits < 20 || cfg->filter_log2_bits > 40)
+        return fail(nullptr, DK_ERR_INVALID_ARG, "filter_log2_bits=%u outside 20..40", cfg->filter_log2_bits);
+    if (cfg->n_hashes < 1 || cfg->n_hashes > 16)
+        return fail(nullptr, DK_ERR_INVALID_ARG, "n_hashes=%u outside 1..16", cfg->n_hashes);
+    if (cfg->min_count < 1) return fail(nullptr, DK_ERR_INVALID_ARG, "min_count must be >= 1");
+    if (cfg->mode > DK_MODE_BUCKETED) return fail(nullptr, DK_ERR_INVALID_ARG, "unknown mode %u", cfg->mode);
+    if (cfg->mode == DK_MODE_BUCKETED && cfg->k > 32)
+        return fail(nullptr, DK_ERR_UNSUPPORTED, "bucketed kernels handle k <= 32 (k=%u)", cfg->k);
+
+    int n_dev = 0;
+    hipError_t r = hipGetDeviceCount(&n_dev);
+    if (r != hipSuccess || n_dev == 0)
+        return fail(nullptr, DK_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU path",
+                    r == hipSuccess ? "device count 0" : hipGetErrorString(r));
+    if (cfg->device_id < 0 || cfg->device_id >= n_dev)
+        return fail(nullptr, DK_ERR_INVALID_ARG, "device_id %d outside 0..%d", cfg->device_id, n_dev - 1);
+
+    dk_engine *e = new (std::nothrow) dk_engine();
+    if (!e) return fail(nullptr, DK_ERR_OOM, "host allocation failed");
+    e->cfg = *cfg;
+    e->device = cfg->device_id;
+    e->own_stream = cfg->stream == nullptr;
+    e->d_ctr = nullptr;
+    e->h_ctr = nullptr;
+    e->n_ev = 0;
+    memset(&e->timings, 0, sizeof e->timings);
+    for (auto &ev : e->ev) ev = nullptr;
+
+    auto bail = [&](const char *what, hipError_t err) {
+        dk_status s = fail(nullptr, DK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
+        dk_engine_destroy(e);
+        return s;
+    };
+    if ((r = hipSetDevice(e->device)) != hipSuccess) return bail("hipSetDevice", r);
+    hipDeviceProp_t prop;
+    if ((r = hipGetDeviceProperties(&prop, e->device)) != hipSuccess) return bail("hipGetDeviceProperties", r);
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (e->own_stream) {
+        if ((r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreate", r);
+    } else {
+        e->stream = (hipStream_t)cfg->stream;
+    }
+    if ((r = hipMalloc((void **)&e->d_ctr, sizeof(Counters))) != hipSuccess) return bail("hipMalloc", r);
+    if ((r = hipHostMalloc((void **)&e->h_ctr, sizeof(Counters), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", r);
+    for (auto &ev : e->ev)
+        if ((r = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", r);
+    *out = e;
+    return DK_OK;
+}
+
+void dk_engine_destroy(dk_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &b : e->pool)
+        if (b.ptr) (void)hipFree(b.ptr);
+    if (e->d_ctr) (void)hipFree(e->d_ctr);
+    if (e->h_ctr) (void)hipHostFree(e->h_ctr);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char *dk_last_error(const dk_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+dk_status dk_engine_synchronize(dk_engine *e)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+dk_status dk_engine_timings(const dk_engine *e, dk_timings *out)
+{
+    if (!e || !out) return DK_ERR_INVALID_ARG;
+    *out = e->timings;
+    return DK_OK;
+}
+
+dk_status dk_engine_config(const dk_engine *e, dk_config *out)
+{
+    if (!e || !out) return DK_ERR_INVALID_ARG;
+    *out = e->cfg;
+    return DK_OK;
+}
+
+// ---- read batches -----------------------------------------------------------------------------
+static dk_status reads_alloc(dk_engine *e, uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out)
+{
+    dk_reads *r = new (std::nothrow) dk_reads();
+    if (!r) return fail(e, DK_ERR_OOM, "host allocation failed");
+    r->e = e;
+    r->n_bases = n_bases;
+    r->n_reads = n_reads;
+    r->n_windows = n_windows;
+    r->owns = true;
+    r->d_bases = r->d_mask = nullptr;
+    const size_t bw = (n_bases + 31) / 32, mw = (n_bases + 63) / 64;
+    dk_status s = pool_alloc(e, (bw + 2) * 8, (void **)&r->d_bases);
+    if (s == DK_OK) s = pool_alloc(e, (mw + 2) * 8, (void **)&r->d_mask);
+    if (s != DK_OK) { dk_reads_destroy(r); return s; }
+    *out = r;
+    return DK_OK;
+}
+
+static uint64_t windows_of(const uint64_t *offsets, uint64_t n_reads, uint32_t k)
+{
+    uint64_t w = 0;
+    for (uint64_t i = 0; i < n_reads; i++) {
+        const uint64_t l = offsets[i + 1] - offsets[i];
+        if (l >= k) w += l - k + 1;
+    }
+    return w;
+}
+
+dk_status dk_reads_from_ascii(dk_engine *e, const uint8_t *seq, const uint64_t *offsets,
+                              uint64_t n_reads, dk_reads **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    CHECK_ARG(e, offsets != nullptr || n_reads == 0);
+    *out = nullptr;
+    DK_HIP(e, hipSetDevice(e->device));
+    for (uint64_t i = 0; i < n_reads; i++) CHECK_ARG(e, offsets[i + 1] >= offsets[i]);
+    const uint64_t n_seq = n_reads ? offsets[n_reads] : 0;
+    CHECK_ARG(e, seq != nullptr || n_seq == 0);
+    const uint64_t n_bases = n_seq + n_reads;
+    dk_reads *r = nullptr;
+    DK_TRY(reads_alloc(e, n_bases, n_reads, windows_of(offsets, n_reads, e->cfg.k), &r));
+    if (n_bases) {
+        uint8_t *d_seq = nullptr;
+        uint64_t *d_off = nullptr;
+        dk_status s = pool_alloc(e, n_seq + 16, (void **)&d_seq);
+        if (s == DK_OK) s = pool_alloc(e, (n_reads + 1) * 8, (void **)&d_off);
+        if (s != DK_OK) { pool_free(e, d_seq); dk_reads_destroy(r); return s; }
+        hipError_t h = hipSuccess;
+        if (n_seq) h = hipMemcpyAsync(d_seq, seq, n_seq, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) h = hipMemcpyAsync(d_off, offsets, (n_reads + 1) * 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) {
+            const uint64_t chunks = (n_bases + 63) / 64;
+            const int grid = (int)((chunks + DIRECT_BLOCK - 1) / DIRECT_BLOCK);
+            pack_ascii_kernel<<<grid, DIRECT_BLOCK, 0, e->stream>>>(d_seq, d_off, n_reads, n_bases, r->d_bases, r->d_mask);
+            h = hipGetLastError();
+        }
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);   // seq/offsets are borrowed only for the call
+        pool_free(e, d_seq);
+        pool_free(e, d_off);
+        if (h != hipSuccess) {
+            dk_reads_destroy(r);
+            return fail(e, DK_ERR_HIP, "packing reads failed: %s", hipGetErrorString(h));
+        }
+    }
+    *out = r;
+    return DK_OK;
+}
+
+dk_status dk_reads_from_packed(dk_engine *e, const uint64_t *bases, const uint64_t *mask,
+                               uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    CHECK_ARG(e, (bases != nullptr && mask != nullptr) || n_bases == 0);
+    *out = nullptr;
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_reads *r = nullptr;
+    DK_TRY(reads_alloc(e, n_bases, n_reads, n_windows, &r));
+    if (n_bases) {
+        hipError_t h = hipMemcpyAsync(r->d_bases, bases, (n_bases + 31) / 32 * 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) h = hipMemcpyAsync(r->d_mask, mask, (n_bases + 63) / 64 * 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+        if (h != hipSuccess) {
+            dk_reads_destroy(r);
+            return fail(e, DK_ERR_HIP, "uploading packed reads failed: %s", hipGetErrorString(h));
+        }
+    }
+    *out = r;
+    return DK_OK;
+}
+
+dk_status dk_reads_attach_device(dk_engine *e, const void *d_bases, const void *d_mask,
+                                 uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    CHECK_ARG(e, (d_bases != nullptr && d_mask != nullptr) || n_bases == 0);
+    dk_reads *r = new (std::nothrow) dk_reads();
+    if (!r) return fail(e, DK_ERR_OOM, "host allocation failed");
+    r->e = e;
+    r->d_bases = (uint64_t *)d_bases;
+    r->d_mask = (uint64_t *)d_mask;
+    r->n_bases = n_bases;
+    r->n_reads = n_reads;
+    r->n_windows = n_windows;
+    r->owns = false;
+    *out = r;
+    return DK_OK;
+}
+
+dk_status dk_reads_synth(dk_engine *e, const dk_synth_config *cfg, int32_t sample,
+                         uint64_t first_read, uint64_t n_reads, dk_reads **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, cfg != nullptr && out != nullptr);
+    CHECK_ARG(e, cfg->struct_size == sizeof(dk_synth_config));
+    CHECK_ARG(e, sample >= 0 && sample <= 2);
+    CHECK_ARG(e, cfg->read_len >= 1 && cfg->genome_len >= cfg->read_len);
+    CHECK_ARG(e, cfg->xover_log2 < 64);
+    *out = nullptr;
+    DK_HIP(e, hipSetDevice(e->device));
+    const uint64_t L = cfg->read_len;
+    const uint64_t n_bases = n_reads * (L + 1);
+    const uint64_t n_windows = L >= e->cfg.k ? n_reads * (L - e->cfg.k + 1) : 0;
+    dk_reads *r = nullptr;
+    DK_TRY(reads_alloc(e, n_bases, n_reads, n_windows, &r));
+    if (n_bases) {
+        SynthParams p;
+        p.seed = cfg->seed;
+        p.genome_len = cfg->genome_len;
+        p.span = cfg->genome_len - L + 1;
+        p.read_len = cfg->read_len;
+        p.xover_log2 = cfg->xover_log2;
+        p.snv_thr = cfg->snv_thr;
+        p.denovo_thr = cfg->denovo_thr;
+        p.err_thr = cfg->err_thr;
+        p.n_thr = cfg->n_thr;
+        p.sample = sample;
+        p.first_read = first_read;
+        p.n_reads = n_reads;
+        const uint64_t chunks = (n_bases + 63) / 64;
+        const uint64_t grid = (chunks + DIRECT_BLOCK - 1) / DIRECT_BLOCK;
+        if (grid > 0x7FFFFFFFULL) { dk_reads_destroy(r); return fail(e, DK_ERR_INVALID_ARG, "synthetic batch too large"); }
+        synth_kernel<<<(int)grid, DIRECT_BLOCK, 0, e->stream>>>(p, n_bases, r->d_bases, r->d_mask);
+        hipError_t h = hipGetLastError();
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+        if (h != hipSuccess) {
+            dk_reads_destroy(r);
+            return fail(e, DK_ERR_HIP, "synthetic read generation failed: %s", hipGetErrorString(h));
+        }
+    }
+    *out = r;
+    return DK_OK;
+}
+
+dk_status dk_reads_stats(const dk_reads *r, dk_stats *out)
+{
+    if (!r || !out) return DK_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->n_reads = r->n_reads;
+    out->n_bases = r->n_bases;
+    out->n_windows = r->n_windows;
+    return DK_OK;
+}
+
+dk_status dk_reads_download(const dk_reads *r, uint64_t *bases, uint64_t *mask)
+{
+    if (!r) return DK_ERR_INVALID_ARG;
+    dk_engine *e = r->e;
+    CHECK_ARG(e, (bases && mask) || r->n_bases == 0);
+    DK_HIP(e, hipSetDevice(e->device));
+    if (r->n_bases) {
+        DK_HIP(e, hipMemcpyAsync(bases, r->d_bases, (r->n_bases + 31) / 32 * 8, hipMemcpyDeviceToHost, e->stream));
+        DK_HIP(e, hipMemcpyAsync(mask, r->d_mask, (r->n_bases + 63) / 64 * 8, hipMemcpyDeviceToHost, e->stream));
+        DK_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    return DK_OK;
+}
+
+void dk_reads_destroy(dk_reads *r)
+{
+    if (!r) return;
+    if (r->owns) {
+        pool_free(r->e, r->d_bases);
+        pool_free(r->e, r->d_mask);
+    }
+    delete r;
+}
+
+uint64_t dk_pack_ascii_host(const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
+                            uint64_t *bases, uint64_t *mask)
+{
+    uint64_t p = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        for (uint64_t j = 0; j <= len; j++, p++) {
+            if ((p & 31) == 0) bases[p >> 5] = 0;
+            if ((p & 63) == 0) mask[p >> 6] = 0;
+            bool flag = true;
+            uint64_t code = 0;
+            if (j < len) {
+                const uint32_t c = seq[offsets[r] + j] & 0xDFu;
+                flag = !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+                code = ((c >> 1) ^ (c >> 2)) & 3u;
+            }
+            if (flag) mask[p >> 6] |= 1ULL << (63 - (p & 63));
+            else bases[p >> 5] |= code << (62 - 2 * (p & 31));
+        }
+    }
+    return p;
+}
+
+// ---- KmerSet -------------------------------------------------------------------------------------
+dk_status dk_set_create(dk_engine *e, dk_set **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    *out = nullptr;
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_set *s = new (std::nothrow) dk_set();
+    if (!s) return fail(e, DK_ERR_OOM, "host allocation failed");
+    s->e = e;
+    s->n_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
+    s->owns = true;
+    s->d_words = nullptr;
+    dk_status st = pool_alloc(e, s->n_bytes, (void **)&s->d_words);
+    if (st != DK_OK) { delete s; return st; }
+    hipError_t h = hipMemsetAsync(s->d_words, 0, s->n_bytes, e->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    if (h != hipSuccess) { dk_set_destroy(s); return fail(e, DK_ERR_HIP, "clearing filter failed: %s", hipGetErrorString(h)); }
+    *out = s;
+    return DK_OK;
+}
+
+dk_status dk_set_attach(dk_engine *e, void *d_filter, dk_set **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr && d_filter != nullptr);
+    CHECK_ARG(e, ((uintptr_t)d_filter & 15) == 0);
+    dk_set *s = new (std::nothrow) dk_set();
+    if (!s) return fail(e, DK_ERR_OOM, "host allocation failed");
+    s->e = e;
+    s->n_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
+    s->owns = false;
+    s->d_words = (unsigned long long *)d_filter;
+    *out = s;
+    return DK_OK;
+}
+
+dk_status dk_set_clear(dk_set *s)
+{
+    if (!s) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemsetAsync(s->d_words, 0, s->n_bytes, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+static bool use_bucketed(const dk_engine *e, const dk_reads *r)
+{
+    if (e->cfg.k > 32) return false;
+    if (e->cfg.mode == DK_MODE_DIRECT) return false;
+    if (e->cfg.mode == DK_MODE_BUCKETED) return true;
+    return dk::bucketed_pays(e, r->n_bases);
+}
+
+dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
+{
+    if (!s || !r) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    CHECK_ARG(e, r->e == e);
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
+    stage_begin(e);
+    if (r->n_bases) {
+        if (use_bucketed(e, r)) {
+            DK_TRY(dk::bucketed_insert(e, s, r));
+        } else {
+            const StreamView sv = view_of(r);
+            const FilterView fv = fview_of(e, s);
+            const int grid = grid_for(e, r->n_bases, DIRECT_BLOCK);
+            if (e->cfg.k > 32)
+                insert_direct_kernel<true><<<grid, DIRECT_BLOCK, 0, e->stream>>>(sv, fv, (int)e->cfg.k, (int)e->cfg.canonical, e->d_ctr);
+            else
+                insert_direct_kernel<false><<<grid, DIRECT_BLOCK, 0, e->stream>>>(sv, fv, (int)e->cfg.k, (int)e->cfg.canonical, e->d_ctr);
+            DK_HIP(e, hipGetLastError());
+            stage_mark(e, "insert_direct");
+        }
+    }
+    DK_TRY(read_counters(e));
+    DK_TRY(stage_end(e));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = r->n_reads;
+        stats->n_bases = r->n_bases;
+        stats->n_windows = r->n_windows;
+        stats->n_valid = e->h_ctr->n_valid;
+    }
+    return DK_OK;
+}
+
+dk_status dk_set_contains(dk_set *s, const uint64_t *kmers_lo, const uint64_t *kmers_hi, uint64_t n, uint8_t *out)
+{
+    if (!s) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    const bool wide = e->cfg.k > 32;
+    CHECK_ARG(e, n == 0 || (kmers_lo && out));
+    CHECK_ARG(e, !wide || n == 0 || kmers_hi);
+    if (n == 0) return DK_OK;
+    DK_HIP(e, hipSetDevice(e->device));
+    uint64_t *d_lo = nullptr, *d_hi = nullptr;
+    uint8_t *d_out = nullptr;
+    dk_status st = pool_alloc(e, n * 8, (void **)&d_lo);
+    if (st == DK_OK && wide) st = pool_alloc(e, n * 8, (void **)&d_hi);
+    if (st == DK_OK) st = pool_alloc(e, n, (void **)&d_out);
+    hipError_t h = hipSuccess;
+    if (st == DK_OK) {
+        h = hipMemcpyAsync(d_lo, kmers_lo, n * 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess && wide) h = hipMemcpyAsync(d_hi, kmers_hi, n * 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) {
+            const FilterView fv = fview_of(e, s);
+            const uint64_t grid = (n + DIRECT_BLOCK - 1) / DIRECT_BLOCK;
+            if (wide) contains_kernel<true><<<(int)grid, DIRECT_BLOCK, 0, e->stream>>>(fv, d_lo, d_hi, n, d_out);
+            else contains_kernel<false><<<(int)grid, DIRECT_BLOCK, 0, e->stream>>>(fv, d_lo, d_hi, n, d_out);
+            h = hipGetLastError();
+        }
+        if (h == hipSuccess) h = hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, e->stream);
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    }
+    pool_free(e, d_lo);
+    pool_free(e, d_hi);
+    pool_free(e, d_out);
+    if (st != DK_OK) return st;
+    if (h != hipSuccess) return fail(e, DK_ERR_HIP, "dk_set_contains failed: %s", hipGetErrorString(h));
+    return DK_OK;
+}
+
+dk_status dk_set_device_ptr(dk_set *s, void **d_filter, uint64_t *n_bytes)
+{
+    if (!s) return DK_ERR_INVALID_ARG;
+    if (d_filter) *d_filter = s->d_words;
+    if (n_bytes) *n_bytes = s->n_bytes;
+    return DK_OK;
+}
+
+dk_status dk_set_download(dk_set *s, uint64_t *words)
+{
+    if (!s || !words) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemcpyAsync(words, s->d_words, s->n_bytes, hipMemcpyDeviceToHost, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+dk_status dk_set_upload(dk_set *s, const uint64_t *words)
+{
+    if (!s || !words) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemcpyAsync(s->d_words, words, s->n_bytes, hipMemcpyHostToDevice, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set)
+{
+    if (!s || !n_bits_set) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
+    const uint64_t n_words = s->n_bytes / 8;
+    popcount_kernel<<<grid_for(e, n_words, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+        (const uint64_t *)s->d_words, n_words, &e->d_ctr->n_valid);
+    DK_HIP(e, hipGetLastError());
+    DK_TRY(read_counters(e));
+    *n_bits_set = e->h_ctr->n_valid;
+    return DK_OK;
+}
+
+dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src, uint64_t n_slices, uint64_t slice_bytes)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, d_dst != nullptr && (d_src != nullptr || n_slices == 0));
+    CHECK_ARG(e, slice_bytes % 16 == 0);
+    CHECK_ARG(e, ((uintptr_t)d_dst & 15) == 0 && ((uintptr_t)d_src & 15) == 0);
+    if (n_slices == 0 || slice_bytes == 0) return DK_OK;
+    DK_HIP(e, hipSetDevice(e->device));
+    const uint64_t vec = slice_bytes / 16;
+    or_slices_kernel<<<grid_for(e, vec, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+        (uint4 *)d_dst, (const uint4 *)d_src, n_slices, vec);
+    DK_HIP(e, hipGetLastError());
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+void dk_set_destroy(dk_set *s)
+{
+    if (!s) return;
+    if (s->owns) pool_free(s->e, s->d_words);
+    delete s;
+}
+
+// ---- membership pass / KmerCounter ----------------------------------------------------------------
+dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, dk_stats *stats)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, r != nullptr && out != nullptr);
+    CHECK_ARG(e, r->e == e && (!s || s->e == e));
+    *out = nullptr;
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_result *res = new (std::nothrow) dk_result();
+    if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
+    res->e = e;
+    res->d_lo = res->d_hi = nullptr;
+    res->d_cnt = nullptr;
+    res->n = 0;
+    res->wide = e->cfg.k > 32;
+    hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+    if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
+    memset(e->h_ctr, 0, sizeof(Counters));
+    stage_begin(e);
+    dk_status st = DK_OK;
+    if (r->n_bases) {
+        if (use_bucketed(e, r)) st = dk::bucketed_probe(e, s, r, res);
+        else if (res->wide) st = probe_direct<true>(e, s, r, res);
+        else st = probe_direct<false>(e, s, r, res);
+    }
+    if (st == DK_OK) st = stage_end(e);
+    if (st != DK_OK) { dk_result_destroy(res); return st; }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = r->n_reads;
+        stats->n_bases = r->n_bases;
+        stats->n_windows = r->n_windows;
+        stats->n_valid = e->h_ctr->n_valid;
+        stats->n_absent = e->h_ctr->n_absent;
+        stats->n_distinct = e->h_ctr->n_distinct;
+        stats->n_emitted = res->n;
+    }
+    *out = res;
+    return DK_OK;
+}
+
+dk_status dk_result_size(const dk_result *res, uint64_t *n)
+{
+    if (!res || !n) return DK_ERR_INVALID_ARG;
+    *n = res->n;
+    return DK_OK;
+}
+
+dk_status dk_result_copy(const dk_result *res, uint64_t *kmers_lo, uint64_t *kmers_hi, uint32_t *counts)
+{
+    if (!res) return DK_ERR_INVALID_ARG;
+    dk_engine *e = res->e;
+    if (res->n == 0) return DK_OK;
+    CHECK_ARG(e, kmers_lo != nullptr && counts != nullptr);
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemcpyAsync(kmers_lo, res->d_lo, res->n * 8, hipMemcpyDeviceToHost, e->stream));
+    if (kmers_hi) {
+        if (res->wide) DK_HIP(e, hipMemcpyAsync(kmers_hi, res->d_hi, res->n * 8, hipMemcpyDeviceToHost, e->stream));
+        else memset(kmers_hi, 0, res->n * 8);
+    } else {
+        CHECK_ARG(e, !res->wide);
+    }
+    DK_HIP(e, hipMemcpyAsync(counts, res->d_cnt, res->n * 4, hipMemcpyDeviceToHost, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+dk_status dk_result_device_view(const dk_result *res, const void **d_kmers_lo, const void **d_kmers_hi,
+                                const void **d_counts, uint64_t *n)
+{
+    if (!res) return DK_ERR_INVALID_ARG;
+    if (d_kmers_lo) *d_kmers_lo = res->d_lo;
+    if (d_kmers_hi) *d_kmers_hi = res->d_hi;
+    if (d_counts) *d_counts = res->d_cnt;
+    if (n) *n = res->n;
+    return DK_OK;
+}
+
+void dk_result_destroy(dk_result *res)
+{
+    if (!res) return;
+    pool_free(res->e, res->d_lo);
+    pool_free(res->e, res->d_hi);
+    pool_free(res->e, res->d_cnt);
+    delete res;
+}
+
+}  // extern "C"

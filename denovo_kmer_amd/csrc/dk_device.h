@@ -1,0 +1,148 @@
+// dk_device.h -- device-side building blocks shared by every kernel of the engine (gfx950).
+//
+// Spec clauses implemented here are those of DESIGN.md section 2 (= SURVEY.md section 9, A-1..A-5);
+// the reference files they stand for (kmer.rs: extraction, canonicalisation, hashing) are not in
+// /root/reference, so there is no file:line to cite.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dk {
+
+constexpr int WAVE = 64;
+
+// ---- spec A-4: murmur3 fmix64 and its inverse (the hash is a bijection on u64, which lets a
+// bucket record carry the hash only and the k-mer be recovered for the rare absent ones) -----
+__host__ __device__ __forceinline__ uint64_t fmix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+__host__ __device__ __forceinline__ uint64_t unfmix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0x9cb4b2f8129337dbULL;   // inverse of 0xc4ceb9fe1a85ec53 mod 2^64
+    x ^= x >> 33;
+    x *= 0x4f74430c22a54005ULL;   // inverse of 0xff51afd7ed558ccd mod 2^64
+    x ^= x >> 33;
+    return x;
+}
+
+struct Kmer {
+    uint64_t hi, lo;
+};
+
+// t-term of the hash: seed for k <= 32; seed ^ fmix64(hi + golden) beyond
+template <bool WIDE>
+__host__ __device__ __forceinline__ uint64_t hash_tweak(uint64_t hi, uint64_t seed)
+{
+    if (WIDE) return seed ^ fmix64(hi + 0x9E3779B97F4A7C15ULL);
+    return seed;
+}
+
+template <bool WIDE>
+__host__ __device__ __forceinline__ uint64_t hash_kmer(Kmer km, uint64_t seed)
+{
+    return fmix64(km.lo ^ hash_tweak<WIDE>(km.hi, seed));
+}
+
+// reverse the order of the 32 two-bit groups of a word
+__device__ __forceinline__ uint64_t rev_pairs64(uint64_t x)
+{
+    uint64_t r = __brevll(x);
+    return ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+}
+
+// ---- window extraction from the packed stream (spec A-1, A-3, A-5) --------------------------
+// W(i) returns word i of the bases stream, M(i) word i of the mask stream; both may be asked for
+// one (WIDE: two) word(s) past the one holding position p, the accessor clamps.
+// Returns true when [p, p+k) holds a k-mer; km = canonical (or forward) k-mer.
+template <bool WIDE, class BasesAt, class MaskAt>
+__device__ __forceinline__ bool extract_kmer(uint64_t p, int k, bool canonical,
+                                             BasesAt W, MaskAt M, Kmer &km)
+{
+    // mask: k flags from bit (p & 63) of word p >> 6, MSB first
+    const uint64_t mw = p >> 6;
+    const int ms = (int)(p & 63);
+    uint64_t mv = M(mw) << ms;
+    if (ms) mv |= M(mw + 1) >> (64 - ms);
+    const bool bad = (mv >> (64 - k)) != 0;
+
+    const uint64_t bw = p >> 5;
+    const int o = 2 * (int)(p & 31);
+    if (!WIDE) {
+        uint64_t v = W(bw) << o;
+        if (o) v |= W(bw + 1) >> (64 - o);
+        const int s = 64 - 2 * k;
+        const uint64_t fwd = v >> s;
+        uint64_t out = fwd;
+        if (canonical) {
+            const uint64_t rc = (~rev_pairs64(fwd)) >> s;
+            out = rc < fwd ? rc : fwd;
+        }
+        km.hi = 0;
+        km.lo = out;
+    } else {
+        const uint64_t w0 = W(bw), w1 = W(bw + 1), w2 = W(bw + 2);
+        uint64_t h = w0 << o, l = w1 << o;
+        if (o) { h |= w1 >> (64 - o); l |= w2 >> (64 - o); }
+        const int s = 128 - 2 * k;             // 0..62 for k in 33..64
+        uint64_t fh = h, fl = l;
+        if (s) { fl = (l >> s) | (h << (64 - s)); fh = h >> s; }
+        uint64_t oh = fh, ol = fl;
+        if (canonical) {
+            // reverse the 64 groups of the right-aligned value, complement, re-align
+            uint64_t rh = ~rev_pairs64(fl), rl = ~rev_pairs64(fh);
+            if (s) { rl = (rl >> s) | (rh << (64 - s)); rh = rh >> s; }
+            if (rh < fh || (rh == fh && rl < fl)) { oh = rh; ol = rl; }
+        }
+        km.hi = oh;
+        km.lo = ol;
+    }
+    return !bad;
+}
+
+// ---- blocked Bloom geometry -----------------------------------------
+// block = top log2_blocks bits of h; bit_j = (a + j*d) & 511, a = h & 511, d = ((h>>9)&511)|1
+__host__ __device__ __forceinline__ uint64_t bloom_block(uint64_t h, int log2_blocks)
+{
+    return log2_blocks > 0 ? (h >> (64 - log2_blocks)) : 0;
+}
+
+// ---- wave-level helpers ---------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ int popc_below(uint64_t ballot)
+{
+    // number of set bits of `ballot` in lanes below this one
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0));
+}
+
+// wave-aggregated append: lanes with pred reserve consecutive slots from *counter.
+// Returns this lane's slot (valid only where pred).
+__device__ __forceinline__ uint64_t wave_append(bool pred, unsigned long long *counter)
+{
+    const uint64_t b = __ballot(pred);
+    const int n = __popcll(b);
+    uint64_t base = 0;
+    if (n) {
+        const int leader = __ffsll((long long)b) - 1;
+        if (lane_id() == leader) base = atomicAdd(counter, (unsigned long long)n);
+        base = __shfl(base, leader);
+    }
+    return base + (uint64_t)popc_below(b);
+}
+
+__device__ __forceinline__ uint64_t wave_sum(uint64_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;   // lane 0 holds the sum
+}
+
+}  // namespace dk

@@ -1,0 +1,357 @@
+// dk_kernels_direct.h -- "direct" kernel family: one thread per stream position, the filter is
+// touched in HBM in place.  Used for small batches (where sweeping the whole filter would cost
+// more than the random accesses), for k > 32, for the overflow records of the bucketed family,
+// and as the A/B baseline of the bucketed family.
+//
+// Roofline: HBM-bound on random 64-B filter blocks; algorithmic bytes per
+// k-mer = 3L/(8(L-k+1)) [2-bit bases + 1-bit mask] + 64 [one filter block] (+64 write-back on insert).
+#pragma once
+#include "dk_device.h"
+
+namespace dk {
+
+constexpr int DIRECT_BLOCK = 256;
+constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
+
+struct StreamView {
+    const uint64_t *bases;
+    const uint64_t *mask;
+    uint64_t n_bases;      // positions incl. separators
+    uint64_t n_bwords;     // ceil(n_bases / 32)
+    uint64_t n_mwords;     // ceil(n_bases / 64)
+};
+
+struct FilterView {
+    unsigned long long *words;   // 2^log2_bits / 64 words
+    int log2_blocks;             // log2_bits - 9
+    int n_hashes;
+    uint64_t seed;
+};
+
+struct Counters {               // device-side statistics of one operation
+    unsigned long long n_valid;
+    unsigned long long n_absent;
+    unsigned long long n_cand;      // candidates appended (direct probe)
+    unsigned long long n_distinct;
+    unsigned long long n_emitted;
+    unsigned long long n_overflow;  // bucketed: records diverted to the overflow list
+    unsigned long long pad[2];
+};
+
+// ---- ASCII -> packed stream ------------------------------------------------------------------
+// one thread per 64 output positions (two bases words, one mask word)
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+pack_ascii_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ offsets,
+                  uint64_t n_reads, uint64_t n_bases, uint64_t *__restrict__ bases,
+                  uint64_t *__restrict__ mask)
+{
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = chunk * 64;
+    if (p0 >= n_bases) return;
+    // read holding p0: largest r with offsets[r] + r <= p0
+    uint64_t lo = 0, hi = n_reads;   // invariant: start(lo) <= p0, answer in [lo, hi)
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (offsets[mid] + mid <= p0) lo = mid; else hi = mid;
+    }
+    uint64_t r = lo;
+    uint64_t rs = offsets[r], re = offsets[r + 1];
+    uint64_t j = p0 - (rs + r);              // position inside read r (== L_r means separator)
+    uint64_t b0 = 0, b1 = 0, m = 0;
+    for (int i = 0; i < 64; i++) {
+        const uint64_t p = p0 + i;
+        if (p >= n_bases) break;
+        bool flag;
+        uint32_t code = 0;
+        if (j == re - rs) {                  // separator after read r
+            flag = true;
+            r++;
+            if (r < n_reads) { rs = re; re = offsets[r + 1]; }
+            j = 0;
+        } else {
+            const uint32_t c = seq[rs + j] & 0xDFu;
+            flag = !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+            code = ((c >> 1) ^ (c >> 2)) & 3u;
+            j++;
+        }
+        if (flag) m |= 1ULL << (63 - i);
+        else if (i < 32) b0 |= (uint64_t)code << (62 - 2 * i);
+        else b1 |= (uint64_t)code << (62 - 2 * (i - 32));
+    }
+    mask[chunk] = m;
+    bases[2 * chunk] = b0;
+    if (p0 + 32 < n_bases) bases[2 * chunk + 1] = b1;
+}
+
+// ---- synthetic trio reads, generated straight into the packed format ----
+struct SynthParams {
+    uint64_t seed, genome_len, span;   // span = genome_len - read_len + 1
+    uint32_t read_len, xover_log2;
+    uint64_t snv_thr, denovo_thr, err_thr, n_thr;
+    int sample;
+    uint64_t first_read, n_reads;
+};
+
+__host__ __device__ __forceinline__ uint64_t splitmix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t stream_key(uint64_t seed, uint64_t stream)
+{
+    return splitmix(seed ^ (stream * 0xD1342543DE82EF95ULL));
+}
+__device__ __forceinline__ int alt_of(uint64_t r) { return 1 + (int)(((r & 0xFFFF) * 3) >> 16); }
+
+struct SynthKeys { uint64_t genome, snv[4], xover[2], denovo, read, err, nn; };
+
+__device__ __forceinline__ int synth_hap_base(const SynthParams &c, const SynthKeys &k, int hid, uint64_t pos)
+{
+    int g = (int)(splitmix(k.genome + pos) & 3);
+    const uint64_t r = splitmix(k.snv[hid] + pos);
+    if (r < c.snv_thr) g = (g + alt_of(r)) & 3;
+    return g;
+}
+
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+synth_kernel(SynthParams c, uint64_t n_bases, uint64_t *__restrict__ bases, uint64_t *__restrict__ mask)
+{
+    const uint64_t chunk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t p0 = chunk * 64;
+    if (p0 >= n_bases) return;
+    SynthKeys k;
+    k.genome = stream_key(c.seed, 1);
+    for (int h = 0; h < 4; h++) k.snv[h] = stream_key(c.seed, 2 + h);
+    k.xover[0] = stream_key(c.seed, 6);
+    k.xover[1] = stream_key(c.seed, 7);
+    k.denovo = stream_key(c.seed, 8);
+    k.read = stream_key(c.seed, 16 + c.sample);
+    k.err = stream_key(c.seed, 32 + c.sample);
+    k.nn = stream_key(c.seed, 48 + c.sample);
+
+    const uint64_t L = c.read_len, stride = L + 1;
+    uint64_t r = p0 / stride, j = p0 % stride;
+    uint64_t start = 0;
+    int which = 0, strand = 0;
+    bool have = false;
+    uint64_t b0 = 0, b1 = 0, m = 0;
+    for (int i = 0; i < 64; i++) {
+        if (p0 + i >= n_bases) break;
+        bool flag = false;
+        int b = 0;
+        if (j == L) {
+            flag = true;
+        } else {
+            const uint64_t ridx = c.first_read + r;
+            if (!have) {
+                const uint64_t u = splitmix(k.read + ridx);
+                which = (int)(u & 1);
+                strand = (int)((u >> 1) & 1);
+                start = __umul64hi(splitmix(u), c.span);
+                have = true;
+            }
+            const uint64_t pos = strand ? start + L - 1 - j : start + j;
+            if (c.sample < 2) {
+                b = synth_hap_base(c, k, 2 * c.sample + which, pos);
+            } else {
+                const uint64_t blk = pos >> c.xover_log2;
+                const int sel = (int)(splitmix(k.xover[which] + blk) & 1);
+                b = synth_hap_base(c, k, 2 * which + sel, pos);
+                if (which == 0) {
+                    const uint64_t d = splitmix(k.denovo + pos);
+                    if (d < c.denovo_thr) b = (b + alt_of(d)) & 3;
+                }
+            }
+            if (strand) b = 3 - b;
+            const uint64_t e = splitmix(k.err + ridx * L + j);
+            if (e < c.err_thr) b = (b + alt_of(e)) & 3;
+            const uint64_t n = splitmix(k.nn + ridx * L + j);
+            if (n < c.n_thr) flag = true;
+        }
+        if (flag) m |= 1ULL << (63 - i);
+        else if (i < 32) b0 |= (uint64_t)b << (62 - 2 * i);
+        else b1 |= (uint64_t)b << (62 - 2 * (i - 32));
+        if (++j == stride) { j = 0; r++; have = false; }
+    }
+    mask[chunk] = m;
+    bases[2 * chunk] = b0;
+    if (p0 + 32 < n_bases) bases[2 * chunk + 1] = b1;
+}
+
+// ---- direct insert ----------------------------------------------------------------------------
+struct GlobalWords {
+    const uint64_t *w;
+    uint64_t last;
+    __device__ __forceinline__ uint64_t operator()(uint64_t i) const { return w[i < last ? i : last]; }
+};
+
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+insert_direct_kernel(StreamView s, FilterView f, int k, int canonical, Counters *ctr)
+{
+    const GlobalWords W{s.bases, s.n_bwords - 1}, M{s.mask, s.n_mwords - 1};
+    uint64_t n_valid = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < s.n_bases; p += stride) {
+        Kmer km;
+        if (!extract_kmer<WIDE>(p, k, canonical, W, M, km)) continue;
+        n_valid++;
+        const uint64_t h = hash_kmer<WIDE>(km, f.seed);
+        unsigned long long *blk = f.words + bloom_block(h, f.log2_blocks) * 8;
+        const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
+        for (int j = 0; j < f.n_hashes; j++) {
+            const uint32_t bit = (a + (uint32_t)j * d) & 511;
+            const unsigned long long m = 1ULL << (bit & 63);
+            // test before set: with 30x coverage most k-mers are already in; a stale read only
+            // costs a redundant atomic
+            if (!(blk[bit >> 6] & m)) atomicOr(&blk[bit >> 6], m);
+        }
+    }
+    n_valid = wave_sum(n_valid);
+    if (lane_id() == 0 && n_valid) atomicAdd(&ctr->n_valid, (unsigned long long)n_valid);
+}
+
+template <bool WIDE>
+__device__ __forceinline__ bool filter_test(const FilterView &f, uint64_t h)
+{
+    const unsigned long long *blk = f.words + bloom_block(h, f.log2_blocks) * 8;
+    const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
+    bool all = true;
+    for (int j = 0; j < f.n_hashes; j++) {
+        const uint32_t bit = (a + (uint32_t)j * d) & 511;
+        all = all && ((blk[bit >> 6] >> (bit & 63)) & 1ULL);
+    }
+    return all;
+}
+
+// ---- direct probe: absent k-mers are appended to the candidate list ----------------------------
+// f.words == nullptr: every valid k-mer is a candidate (KmerCounter semantics)
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+probe_direct_kernel(StreamView s, FilterView f, int k, int canonical, Counters *ctr,
+                    uint64_t *__restrict__ cand_lo, uint64_t *__restrict__ cand_hi, uint64_t cand_cap)
+{
+    const GlobalWords W{s.bases, s.n_bwords - 1}, M{s.mask, s.n_mwords - 1};
+    uint64_t n_valid = 0, n_absent = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (s.n_bases + 63) & ~63ULL;       // keep whole waves in the loop
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_round; p += stride) {
+        Kmer km;
+        bool valid = false;
+        if (p < s.n_bases) valid = extract_kmer<WIDE>(p, k, canonical, W, M, km);
+        bool absent = false;
+        if (valid) {
+            n_valid++;
+            absent = f.words ? !filter_test<WIDE>(f, hash_kmer<WIDE>(km, f.seed)) : true;
+        }
+        const uint64_t slot = wave_append(absent, &ctr->n_cand);
+        if (absent) {
+            n_absent++;
+            if (slot < cand_cap) {
+                cand_lo[slot] = km.lo;
+                if (WIDE) cand_hi[slot] = km.hi;
+            }
+        }
+    }
+    n_valid = wave_sum(n_valid);
+    n_absent = wave_sum(n_absent);
+    if (lane_id() == 0) {
+        if (n_valid) atomicAdd(&ctr->n_valid, (unsigned long long)n_valid);
+        if (n_absent) atomicAdd(&ctr->n_absent, (unsigned long long)n_absent);
+    }
+}
+
+// ---- exact counting of the candidates: open-addressing table of candidate indices --------------
+// A slot holds the index of the first candidate that claimed it; key comparison reads the
+// (immutable) candidate arrays, so 64- and 128-bit keys share one lock-free protocol.
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+count_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,
+                    uint64_t n_cand, uint32_t *slots, uint32_t *counts, int log2_cap, uint64_t seed)
+{
+    const uint64_t cap_mask = (1ULL << log2_cap) - 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += stride) {
+        Kmer km{WIDE ? cand_hi[i] : 0, cand_lo[i]};
+        uint64_t s = hash_kmer<WIDE>(km, seed) >> (64 - log2_cap);
+        for (;;) {
+            uint32_t cur = slots[s];
+            if (cur == SLOT_EMPTY) cur = atomicCAS(&slots[s], SLOT_EMPTY, (uint32_t)i);
+            if (cur == SLOT_EMPTY) break;                       // claimed
+            if (cand_lo[cur] == km.lo && (!WIDE || cand_hi[cur] == km.hi)) break;
+            s = (s + 1) & cap_mask;
+        }
+        atomicAdd(&counts[s], 1u);
+    }
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+count_emit_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,
+                  const uint32_t *__restrict__ slots, const uint32_t *__restrict__ counts,
+                  uint64_t cap, uint32_t min_count, Counters *ctr,
+                  uint64_t *__restrict__ out_lo, uint64_t *__restrict__ out_hi,
+                  uint32_t *__restrict__ out_cnt)
+{
+    uint64_t n_distinct = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (cap + 63) & ~63ULL;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_round; s += stride) {
+        uint32_t idx = SLOT_EMPTY, c = 0;
+        if (s < cap) idx = slots[s];
+        if (idx != SLOT_EMPTY) { c = counts[s]; n_distinct++; }
+        const bool emit = idx != SLOT_EMPTY && c >= min_count;
+        const uint64_t o = wave_append(emit, &ctr->n_emitted);
+        if (emit) {
+            out_lo[o] = cand_lo[idx];
+            if (WIDE) out_hi[o] = cand_hi[idx];
+            out_cnt[o] = c;
+        }
+    }
+    n_distinct = wave_sum(n_distinct);
+    if (lane_id() == 0 && n_distinct) atomicAdd(&ctr->n_distinct, (unsigned long long)n_distinct);
+}
+
+// ---- KmerSet::contains for explicit k-mers -----------------------------------------------------
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+contains_kernel(FilterView f, const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                uint64_t n, uint8_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Kmer km{WIDE ? hi[i] : 0, lo[i]};
+    out[i] = filter_test<WIDE>(f, hash_kmer<WIDE>(km, f.seed)) ? 1 : 0;
+}
+
+// ---- filter utilities ---------------------------------------------------------------------------
+// dst[i] |= OR_j src[j * slice_vec + i], 16 bytes per lane
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+or_slices_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint64_t n_slices, uint64_t slice_vec)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slice_vec; i += stride) {
+        uint4 acc = dst[i];
+        for (uint64_t j = 0; j < n_slices; j++) {
+            const uint4 v = src[j * slice_vec + i];
+            acc.x |= v.x; acc.y |= v.y; acc.z |= v.z; acc.w |= v.w;
+        }
+        dst[i] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+popcount_kernel(const uint64_t *__restrict__ words, uint64_t n_words, unsigned long long *out)
+{
+    uint64_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+        acc += (uint64_t)__popcll(words[i]);
+    acc = wave_sum(acc);
+    if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+
+}  // namespace dk

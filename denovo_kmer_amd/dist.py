@@ -1,0 +1,78 @@
+"""Multi-GPU host logic: read sharding and the OR-all-reduce of the parent filter.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  The hot path shards
+by reads with one exchange step: every rank builds a partial parent filter of the FULL size from
+its parent-read shard, the partial filters are OR-combined, then every rank probes its child
+shard locally.  RCCL has no bitwise-OR reduction (ncclRedOp_t = sum/prod/max/min/avg), so the
+all-reduce is composed:
+
+    all_to_all_single   rank r receives slice r of every rank's filter      (P-1)/P * M bytes out
+    local OR            HIP kernel dk_or_reduce_slices over the P slices
+    all_gather          every rank receives every reduced slice            (P-1)/P * M bytes in
+
+On a fully connected xGMI node each phase uses all 7 links of a GPU at once, which is why this
+shape is used instead of a ring.  torch is plumbing only (device memory + collectives).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world_size):
+    """contiguous shard [lo, hi) of n_items for `rank`; shards differ by at most one item"""
+    base, rem = divmod(n_items, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def hip_or_fn(engine):
+    """local OR step on the GPU through the C ABI (dk_or_reduce_slices)"""
+    def fn(dst, src, n_slices):
+        torch.cuda.synchronize()            # collectives ran on torch's stream, the kernel on the engine's
+        engine.or_reduce_slices(dst.data_ptr(), src.data_ptr(), n_slices, dst.numel() * dst.element_size())
+    return fn
+
+
+def or_allreduce_(filt, or_fn, group=None):
+    """In-place bitwise-OR all-reduce of `filt` (1-D int64 tensor, one per rank, equal sizes).
+
+    or_fn(dst, src, n_slices): dst |= OR of the n_slices contiguous slices in src.
+    Returns bytes sent per rank (for bandwidth reporting)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 0
+    assert filt.dim() == 1 and filt.is_contiguous() and filt.dtype == torch.int64
+    n = filt.numel()
+    assert n % (2 * world) == 0, "filter words must split into 16-byte-aligned slices per rank"
+    sl = n // world
+    recv = torch.empty_like(filt)
+    dist.all_to_all_single(recv, filt, group=group)          # recv[j*sl:(j+1)*sl] = rank j's slice `rank`
+    reduced = recv[:sl]
+    or_fn(reduced, recv[sl:], world - 1)
+    dist.all_gather_into_tensor(filt, reduced, group=group)
+    return 2 * (world - 1) * sl * filt.element_size()
+
+
+def merge_counts(hi, lo, cnt, min_count=1, group=None):
+    """Gather per-rank (k-mer, count) lists to every rank and sum counts per k-mer.
+
+    A child k-mer can be seen by several ranks (reads are sharded, not k-mers), so the per-rank
+    child-only tables are concatenated and reduced by key.  Ranks must run their engines with
+    min_count=1; the threshold is applied here, after the sum.  Inputs/outputs are numpy arrays;
+    the lists are small next to the reads."""
+    import numpy as np
+    world = dist.get_world_size(group)
+    parts = [None] * world
+    dist.all_gather_object(parts, (np.asarray(hi), np.asarray(lo), np.asarray(cnt)), group=group)
+    ahi = np.concatenate([p[0] for p in parts]).astype(np.uint64)
+    alo = np.concatenate([p[1] for p in parts]).astype(np.uint64)
+    acnt = np.concatenate([p[2] for p in parts]).astype(np.uint64)
+    if len(alo) == 0:
+        return ahi, alo, acnt.astype(np.uint32)
+    order = np.lexsort((alo, ahi))
+    ahi, alo, acnt = ahi[order], alo[order], acnt[order]
+    new = np.ones(len(alo), dtype=bool)
+    new[1:] = (ahi[1:] != ahi[:-1]) | (alo[1:] != alo[:-1])
+    idx = np.flatnonzero(new)
+    sums = np.add.reduceat(acnt, idx)
+    keep = sums >= min_count
+    return ahi[idx][keep], alo[idx][keep], np.minimum(sums[keep], 0xFFFFFFFF).astype(np.uint32)

@@ -1,0 +1,164 @@
+/*
+ * denovo_kmer.h -- C ABI of the MI355X-native de-novo k-mer engine (libdenovo_kmer.so).
+ *
+ * Drop-in boundary for the hot path BASELINE.json names: k-mer extraction / canonicalisation /
+ * hashing (reference: kmer.rs -- NOT IN MOUNT) and parent-set membership + child-only counting
+ * (reference: counter.rs, types KmerCounter / KmerSet -- NOT IN MOUNT).  /root/reference holds
+ * only .gitignore:1 and .github/workflows/ci.yml:1-50, so no reference FFI exists to cite; the
+ * reference interface each entry point stands in for is named by type (KmerSet::insert, ...),
+ * as reconstructed in SURVEY.md section 8b.  A Rust host binds this header 1:1 with an
+ * `extern "C"` block; no C++ types, exceptions or callbacks cross it.
+ *
+ * Conventions
+ *  - every call returns a dk_status (0 = DK_OK); dk_last_error(engine) gives the message
+ *  - one engine = one GPU + one HIP stream; calls on one engine are serialised by the caller
+ *    (Rust: Send, not Sync); engines on different devices are independent
+ *  - input pointers are borrowed for the duration of the call; handles are owned by the library
+ *  - k-mers: A=0 C=1 G=2 T=3, first base most significant; lo = low 64 bits, hi = bits above
+ *    (hi = 0 for k <= 32); canonical = min(forward, reverse complement)
+ *
+ * Packed read batch ("dk_reads"), also accepted from the caller:
+ *    bases : u64 words, 32 bases per word, base i of the stream at bits [62-2*(i%32), +2) of
+ *            word i/32 (first base in the most significant bits)
+ *    mask  : u64 words, 64 flags per word, flag i at bit 63-(i%64) of word i/64; 1 = this
+ *            position is not A/C/G/T (N) or is a read separator
+ *    every read is followed by exactly one separator position (mask = 1, base bits ignored);
+ *    n_bases counts separators: n_bases = sum(L_i) + n_reads.
+ *  A window [p, p+k) is a k-mer iff none of its k mask flags is set.
+ */
+#ifndef DENOVO_KMER_H
+#define DENOVO_KMER_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DK_ABI_VERSION 1
+
+typedef int32_t dk_status;
+enum {
+    DK_OK = 0,
+    DK_ERR_INVALID_ARG = 1,
+    DK_ERR_NO_DEVICE = 2,      /* no HIP device / HIP runtime failure at init: never a CPU fallback */
+    DK_ERR_HIP = 3,
+    DK_ERR_OOM = 4,
+    DK_ERR_UNSUPPORTED = 5,
+    DK_ERR_OVERFLOW = 6
+};
+
+enum { DK_MODE_AUTO = 0, DK_MODE_DIRECT = 1, DK_MODE_BUCKETED = 2 };
+
+typedef struct dk_engine dk_engine;
+typedef struct dk_reads dk_reads;     /* device-resident packed read batch */
+typedef struct dk_set dk_set;         /* KmerSet: parent blocked-Bloom filter resident in HBM */
+typedef struct dk_result dk_result;   /* k-mer -> count table (child-only set, or KmerCounter output) */
+
+typedef struct dk_config {
+    uint64_t struct_size;        /* = sizeof(dk_config); versions the struct */
+    uint32_t k;                  /* 1..64 */
+    uint32_t canonical;          /* 1 = strand-neutral (default), 0 = forward only */
+    uint32_t filter_log2_bits;   /* 20..40: filter holds 2^n bits */
+    uint32_t n_hashes;           /* 1..16 bits set per k-mer inside its 512-bit block */
+    uint64_t seed;
+    uint32_t min_count;          /* emit child-only k-mers seen >= min_count times (>=1) */
+    int32_t  device_id;
+    uint32_t rank, world_size;   /* informational; sharding is done by the host */
+    uint32_t mode;               /* DK_MODE_* : kernel family for insert / probe */
+    void    *stream;             /* optional hipStream_t to run on; NULL = engine-owned stream */
+} dk_config;
+
+typedef struct dk_stats {
+    uint64_t n_reads;
+    uint64_t n_bases;       /* stream positions incl. separators */
+    uint64_t n_windows;     /* sum max(0, L-k+1): the k-mers/sec denominator */
+    uint64_t n_valid;       /* windows without N */
+    uint64_t n_absent;      /* probe/count: valid windows absent from the set */
+    uint64_t n_distinct;    /* probe/count: distinct absent k-mers (before min_count) */
+    uint64_t n_emitted;     /* probe/count: k-mers in the result (after min_count) */
+} dk_stats;
+
+#define DK_MAX_STAGES 12
+typedef struct dk_timings {
+    uint32_t n_stages;
+    float    total_ms;                  /* first event to last event of the last operation */
+    float    stage_ms[DK_MAX_STAGES];   /* HIP-event time of each stage on the engine stream */
+    char     stage_name[DK_MAX_STAGES][24];
+} dk_timings;
+
+/* synthetic trio generator; thresholds are rate * 2^64 */
+typedef struct dk_synth_config {
+    uint64_t struct_size;
+    uint64_t seed;
+    uint64_t genome_len;
+    uint32_t read_len;
+    uint32_t xover_log2;        /* crossover block = 2^xover_log2 bases */
+    uint64_t snv_thr, denovo_thr, err_thr, n_thr;
+} dk_synth_config;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int32_t     dk_abi_version(void);
+const char *dk_status_string(dk_status s);
+
+/* ---- engine (replaces: construction of KmerCounter/KmerSet with k, counter.rs) -------------- */
+dk_status   dk_engine_create(const dk_config *cfg, dk_engine **out);
+void        dk_engine_destroy(dk_engine *e);
+const char *dk_last_error(const dk_engine *e);          /* e may be NULL: last create error */
+dk_status   dk_engine_synchronize(dk_engine *e);
+dk_status   dk_engine_timings(const dk_engine *e, dk_timings *out);   /* of the last insert/probe/count */
+dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
+
+/* ---- read batches (replaces: the &[u8] read sequences handed to kmer.rs by the BAM loop) --- */
+/* ASCII reads, concatenated, offsets[n_reads+1]; packed on the GPU */
+dk_status dk_reads_from_ascii(dk_engine *e, const uint8_t *seq, const uint64_t *offsets,
+                              uint64_t n_reads, dk_reads **out);
+/* host buffers already in the packed format above (copied to the device) */
+dk_status dk_reads_from_packed(dk_engine *e, const uint64_t *bases, const uint64_t *mask,
+                               uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out);
+/* device buffers already in the packed format (borrowed, not copied, not freed) */
+dk_status dk_reads_attach_device(dk_engine *e, const void *d_bases, const void *d_mask,
+                                 uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out);
+/* synthetic reads first_read .. first_read+n_reads of sample (0,1 = parents, 2 = child), generated on the GPU */
+dk_status dk_reads_synth(dk_engine *e, const dk_synth_config *cfg, int32_t sample,
+                         uint64_t first_read, uint64_t n_reads, dk_reads **out);
+dk_status dk_reads_stats(const dk_reads *r, dk_stats *out);    /* n_reads, n_bases, n_windows */
+/* copy the packed words back (bases: ceil(n_bases/32) words, mask: ceil(n_bases/64) words) */
+dk_status dk_reads_download(const dk_reads *r, uint64_t *bases, uint64_t *mask);
+void      dk_reads_destroy(dk_reads *r);
+/* host-side packer (no GPU): returns n_bases; bases/mask sized as for dk_reads_download */
+uint64_t  dk_pack_ascii_host(const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
+                             uint64_t *bases, uint64_t *mask);
+
+/* ---- KmerSet (replaces: KmerSet in counter.rs -- insert / contains / union) ----------------- */
+dk_status dk_set_create(dk_engine *e, dk_set **out);                 /* zeroed, library-owned */
+dk_status dk_set_attach(dk_engine *e, void *d_filter, dk_set **out); /* caller-owned device memory of 2^n/8 bytes */
+dk_status dk_set_clear(dk_set *s);
+dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats);      /* KmerSet::insert over all windows */
+dk_status dk_set_contains(dk_set *s, const uint64_t *kmers_lo, const uint64_t *kmers_hi /* NULL if k<=32 */,
+                          uint64_t n, uint8_t *out);                         /* KmerSet::contains */
+dk_status dk_set_device_ptr(dk_set *s, void **d_filter, uint64_t *n_bytes);
+dk_status dk_set_download(dk_set *s, uint64_t *words);               /* 2^n/64 words */
+dk_status dk_set_upload(dk_set *s, const uint64_t *words);
+dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set);
+/* dst[i] |= src[j*slice_words + i] for j < n_slices: the local step of the OR-all-reduce
+ * (RCCL has no bitwise-OR reduction; the host composes all-to-all -> this -> all-gather) */
+dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src,
+                              uint64_t n_slices, uint64_t slice_bytes);
+void      dk_set_destroy(dk_set *s);
+
+/* ---- membership pass + KmerCounter (replaces: child loop of counter.rs) ---------------------- */
+/* probe every window of r against s; absent k-mers are counted.  s == NULL counts every k-mer
+ * of the batch (KmerCounter semantics). */
+dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, dk_stats *stats);
+dk_status dk_result_size(const dk_result *res, uint64_t *n);
+/* unordered copy to host; kmers_hi may be NULL when k <= 32 */
+dk_status dk_result_copy(const dk_result *res, uint64_t *kmers_lo, uint64_t *kmers_hi, uint32_t *counts);
+dk_status dk_result_device_view(const dk_result *res, const void **d_kmers_lo, const void **d_kmers_hi,
+                                const void **d_counts, uint64_t *n);
+void      dk_result_destroy(dk_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENOVO_KMER_H */

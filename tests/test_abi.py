@@ -1,0 +1,86 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/denovo_kmer.h declares, refuses to run without a GPU (no CPU fallback), and its one
+host-only utility (the packer) agrees with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, random_reads
+from denovo_kmer_amd import _lib
+from oracle import orc
+
+HEADER = os.path.join(ROOT, "include", "denovo_kmer.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.dk_abi_version() == _lib.ABI_VERSION
+    assert lib.dk_status_string(0) == b"ok"
+
+
+def test_struct_sizes_match_header():
+    # field-by-field layout is plain C; these sizes are what a Rust #[repr(C)] mirror must have
+    assert C.sizeof(_lib.DkConfig) == 64
+    assert C.sizeof(_lib.DkStats) == 56
+    assert C.sizeof(_lib.DkSynthConfig) == 64
+    assert C.sizeof(_lib.DkTimings) == 8 + 4 * 12 + 24 * 12
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_create_fails_loudly_without_gpu():
+    from denovo_kmer_amd import DkError, Engine
+    with pytest.raises(DkError) as ei:
+        Engine(k=31)
+    assert ei.value.status == _lib.DK_ERR_NO_DEVICE
+    assert "no CPU path" in str(ei.value)
+
+
+def test_engine_create_rejects_bad_config():
+    lib = _lib.load()
+    h = C.c_void_p()
+    for field, value in (("k", 0), ("k", 65), ("filter_log2_bits", 19), ("filter_log2_bits", 41),
+                         ("n_hashes", 0), ("n_hashes", 17), ("min_count", 0), ("mode", 9), ("struct_size", 8)):
+        cfg = _lib.DkConfig(C.sizeof(_lib.DkConfig), 31, 1, 24, 4, 1, 1, 0, 0, 1, 0, None)
+        setattr(cfg, field, value)
+        assert lib.dk_engine_create(C.byref(cfg), C.byref(h)) == _lib.DK_ERR_INVALID_ARG, field
+        assert not h.value
+        assert lib.dk_last_error(None)
+    assert lib.dk_engine_create(None, C.byref(h)) == _lib.DK_ERR_INVALID_ARG
+
+
+def test_host_packer_matches_oracle(rng):
+    from denovo_kmer_amd import pack_ascii_host
+    reads = random_reads(rng, 50, 0, 200, n_rate=0.03, lower_rate=0.2) + ["", "N", "acgt", ""]
+    seq, off = orc.concat_reads(reads)
+    b, m, n = pack_ascii_host(seq, off)
+    ob, om, on = orc.pack_reads(seq, off)
+    assert n == on and np.array_equal(b, ob) and np.array_equal(m, om)
+
+
+def test_product_code_never_imports_the_oracle():
+    # the oracle is test infrastructure: nothing under denovo_kmer_amd/ or include/ may reference it
+    bad = []
+    for base in ("denovo_kmer_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c")):
+                    text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                    if re.search(r"(from|import)\s+oracle|dk_oracle|orc_", text):
+                        bad.append(os.path.join(dirpath, fn))
+    assert not bad, bad
