@@ -13,8 +13,8 @@ import numpy as np
 from . import _lib
 from ._lib import DkConfig, DkStats, DkSynthConfig, DkTimings, check
 
-# kernel families smoke() and the GPU tests sweep ("bucketed" joins once its kernels land)
-SMOKE_MODES = ("direct",)
+# kernel families smoke() and the GPU tests sweep
+SMOKE_MODES = ("direct", "bucketed")
 
 _CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
 _BASE = "ACGT"

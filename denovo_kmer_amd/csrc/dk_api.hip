@@ -607,9 +607,20 @@ dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
     DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
     stage_begin(e);
     if (r->n_bases) {
-        if (use_bucketed(e, r)) {
-            DK_TRY(dk::bucketed_insert(e, s, r));
-        } else {
+        bool direct = !use_bucketed(e, r);
+        if (!direct) {
+            const dk_status bs = dk::bucketed_insert(e, s, r);
+            if (bs == DK_ERR_OVERFLOW) {
+                // a bin overflowed (heavy-hitter k-mers): redo the batch with the direct family;
+                // records already ORed in are harmless
+                DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
+                stage_mark(e, "overflow_redo");
+                direct = true;
+            } else if (bs != DK_OK) {
+                return bs;
+            }
+        }
+        if (direct) {
             const StreamView sv = view_of(r);
             const FilterView fv = fview_of(e, s);
             const int grid = grid_for(e, r->n_bases, DIRECT_BLOCK);
@@ -756,9 +767,23 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
     stage_begin(e);
     dk_status st = DK_OK;
     if (r->n_bases) {
-        if (use_bucketed(e, r)) st = dk::bucketed_probe(e, s, r, res);
-        else if (res->wide) st = probe_direct<true>(e, s, r, res);
-        else st = probe_direct<false>(e, s, r, res);
+        bool direct = !use_bucketed(e, r);
+        if (!direct) {
+            st = dk::bucketed_probe(e, s, r, res);
+            if (st == DK_ERR_OVERFLOW) {
+                // exactness first: drop the partial result and redo the batch with the direct family
+                pool_free(e, res->d_lo);
+                pool_free(e, res->d_cnt);
+                res->d_lo = nullptr;
+                res->d_cnt = nullptr;
+                res->n = 0;
+                h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+                st = h == hipSuccess ? DK_OK : fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h));
+                stage_mark(e, "overflow_redo");
+                direct = true;
+            }
+        }
+        if (direct && st == DK_OK) st = res->wide ? probe_direct<true>(e, s, r, res) : probe_direct<false>(e, s, r, res);
     }
     if (st == DK_OK) st = stage_end(e);
     if (st != DK_OK) { dk_result_destroy(res); return st; }

@@ -17,7 +17,7 @@ from oracle import orc
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "small_trios.json")
-MODES = ["direct"]   # "bucketed" joins once its kernels land
+MODES = ["direct", "bucketed"]
 
 
 def dk():
@@ -41,13 +41,26 @@ def oracle_trio(parents, child, k, log2_bits, nh, seed, canonical=True, min_coun
     return f, ist, km, cn, pst
 
 
+def assert_family_ran(eng):
+    """the kernel family the engine was asked for is the one that produced the last result"""
+    names = [n for n, _ in eng.timings()["stages"]]
+    if not names:
+        return
+    if eng.mode == "bucketed":
+        assert "overflow_redo" not in names and names[0] == "scan_part", names
+    elif eng.mode == "direct":
+        assert names[0] in ("insert_direct", "probe_direct"), names
+
+
 def gpu_trio(eng, parents, child):
     d = dk()
     ks = d.KmerSet(eng)
     pb = d.ReadBatch.from_sequences(eng, parents)
     ist = ks.insert_reads(pb)
+    assert_family_ran(eng)
     cb = d.ReadBatch.from_sequences(eng, child)
     res = d.KmerCounter(eng).child_only(cb, ks)
+    assert_family_ran(eng)
     return ks, ist, res
 
 
@@ -311,6 +324,53 @@ def test_synthetic_trio_parity_config0_scale(mode, k, log2_bits):
         assert_result_equals(res, km, cn)
         assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
         assert eng.timings()["total_ms"] > 0
+
+
+@pytest.mark.parametrize("log2_bits", [29, 31])
+def test_two_level_partition_large_filter(log2_bits):
+    # filters above 2^9 segments take the two-level multisplit (scan_part + repart)
+    d = dk()
+    n_reads, k = 30_000, 31
+    ocfg = orc.synth_cfg(genome_len=300_000)
+    gcfg = d.synth_config(genome_len=300_000)
+    with make_engine("bucketed", k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=77) as eng:
+        ks = d.KmerSet(eng)
+        f = orc.new_filter(log2_bits)
+        for s in (0, 1):
+            ist = ks.insert_reads(d.ReadBatch.synth(eng, gcfg, s, 0, n_reads))
+            seq, off = orc.synth_reads(ocfg, s, 0, n_reads)
+            oist = orc.bloom_insert(f, log2_bits, 4, 77, k, True, seq, off)
+            assert ist["n_valid"] == oist["n_valid"]
+        assert [n for n, _ in eng.timings()["stages"]] == ["scan_part", "repart", "seg_insert"]
+        assert np.array_equal(ks.to_host(), f)
+        res = d.KmerCounter(eng).child_only(d.ReadBatch.synth(eng, gcfg, 2, 0, n_reads), ks)
+        assert [n for n, _ in eng.timings()["stages"]] == ["scan_part", "repart", "seg_probe", "seg_count"]
+        cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+        km, cn, pst = orc.bloom_probe(f, log2_bits, 4, 77, k, True, cseq, coff)
+        assert_result_equals(res, km, cn)
+        assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
+
+
+def test_heavy_hitter_overflow_falls_back_exactly():
+    # one k-mer repeated far beyond its segment's capacity overflows a bin; the engine must
+    # detect it and redo the batch with the direct family, with identical results
+    d = dk()
+    k = 21
+    reads = ["A" * 150] * 4000 + ["ACGTTGCATGCCGATAGCTAGCTAGGATCGATCGATTAGC" * 3] * 10
+    seq, off = orc.concat_reads(reads)
+    with make_engine("bucketed", k=k, filter_log2_bits=24, n_hashes=4, seed=5) as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(reads[:2000])
+        assert "overflow_redo" in [n for n, _ in eng.timings()["stages"]]
+        f = orc.new_filter(24)
+        s2, o2 = orc.concat_reads(reads[:2000])
+        orc.bloom_insert(f, 24, 4, 5, k, True, s2, o2)
+        assert np.array_equal(ks.to_host(), f)
+        res = d.KmerCounter(eng).count_sequences(reads)
+        assert "overflow_redo" in [n for n, _ in eng.timings()["stages"]]
+        km, cn, st = orc.count_reads(k, True, seq, off)
+        assert_result_equals(res, km, cn)
+        assert int(cn.max()) == 4000 * 130
 
 
 @pytest.mark.parametrize("mode", MODES)
