@@ -15,6 +15,7 @@
 // 64-B block per k-mer.
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 
 #include "dk_internal.h"
 
@@ -73,93 +74,147 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
     return wave_sums[wave] + inc - v;
 }
 
-// ---- shared multisplit tail: scatter a tile's records (hs/rk registers) by bin and write the
-// runs to HBM.  bin_of(h) gives the bin; out index = (bin_base + bin) * cap + position in bin. -----
+// ---- shared multisplit tail ------------------------------------------------------------------------
+// A tile's records sit in registers (hs = hash, rk = rank inside its bin from the LDS count).
+// Wave 0 turns the per-bin counts into tile offsets and reserves the global ranges; the global
+// atomics stay in flight while every wave scatters its records into the LDS stage, and only the
+// copy-out needs their result.  Three barriers per tile (A: counts done - by the caller,
+// B: offsets ready, C: stage + global bases ready); the next tile's count phase needs no barrier
+// because it touches only cnt[], which wave 0 re-zeroes before B.
+template <int THREADS, int PER_THREAD>
 struct SplitLds {
-    uint64_t stage[PART_TILE];
-    uint32_t cnt[MAX_BINS];
+    uint64_t stage[THREADS * PER_THREAD];
+    uint32_t cnt[MAX_BINS];     // must be zero on entry to the first tile
     uint32_t off[MAX_BINS];
-    uint32_t gbase[MAX_BINS];
-    uint32_t wave_sums[PART_THREADS / 64];
+    uint32_t delta[MAX_BINS];   // global index in bin = stage index + delta[bin]  (mod 2^32)
     uint32_t total;
 };
 
-template <class BinOf>
-__device__ __forceinline__ void multisplit_flush(SplitLds &L, const uint64_t (&hs)[PART_PER_THREAD],
-                                                 const uint32_t (&rk)[PART_PER_THREAD], int nbins, BinOf bin_of,
+constexpr int MAX_BINS_PER_LANE = MAX_BINS / 64;
+
+template <int THREADS, int PER_THREAD, class BinOf>
+__device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &L, const uint64_t (&hs)[PER_THREAD],
+                                                 const uint32_t (&rk)[PER_THREAD], int nbins, BinOf bin_of,
                                                  uint32_t *cursor, int cursor_stride, uint64_t bin_base,
                                                  uint32_t cap, uint64_t *__restrict__ out,
                                                  uint32_t &n_records, uint32_t &n_overflow)
 {
     const int tid = (int)threadIdx.x;
-    const uint32_t v = tid < nbins ? L.cnt[tid] : 0;
-    const uint32_t ex = block_excl_scan(v, L.wave_sums, &L.total);
-    if (tid < nbins) {
-        L.off[tid] = ex;
-        if (v) L.gbase[tid] = atomicAdd(&cursor[(uint64_t)tid * cursor_stride], v);
-    }
-    __syncthreads();
+    const bool w0 = tid < 64;
+    const int m = nbins > 64 ? nbins / 64 : 1;          // bins per lane of wave 0
+    const int first = tid * m;
+    uint32_t g[MAX_BINS_PER_LANE];                      // the only state wave 0 carries across barrier B
+    if (w0) {
+        uint32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < PART_PER_THREAD; j++)
+        for (int q = 0; q < MAX_BINS_PER_LANE; q++) {
+            if (q < m && first + q < nbins) { L.off[first + q] = sum; sum += L.cnt[first + q]; }
+        }
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (tid >= o) inc += t;
+        }
+        const uint32_t lane_base = inc - sum;
+        if (tid == 63) L.total = inc;
+#pragma unroll
+        for (int q = 0; q < MAX_BINS_PER_LANE; q++) {
+            g[q] = 0;
+            if (q < m && first + q < nbins) {
+                const uint32_t c = L.cnt[first + q];
+                L.cnt[first + q] = 0;
+                L.off[first + q] += lane_base;
+                if (c) g[q] = atomicAdd(&cursor[(uint64_t)(first + q) * cursor_stride], c);
+            }
+        }
+    }
+    __syncthreads();                                     // B
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; j++)
         if (rk[j] != NO_RANK) L.stage[L.off[bin_of(hs[j])] + rk[j]] = hs[j];
-    __syncthreads();
+    if (w0) {
+#pragma unroll
+        for (int q = 0; q < MAX_BINS_PER_LANE; q++)
+            if (q < m && first + q < nbins) L.delta[first + q] = g[q] - L.off[first + q];
+    }
+    __syncthreads();                                     // C
     const uint32_t total = L.total;
-    for (uint32_t i = tid; i < total; i += PART_THREADS) {
+    for (uint32_t i = tid; i < total; i += THREADS) {
         const uint64_t h = L.stage[i];
         const uint32_t bin = bin_of(h);
-        const uint32_t idx = L.gbase[bin] + (i - L.off[bin]);
+        const uint32_t idx = i + L.delta[bin];
         if (idx < cap) out[(bin_base + bin) * cap + idx] = h;
         else n_overflow++;
     }
     if (tid == 0) n_records += total;
-    __syncthreads();
 }
 
 // ---- level 1: packed stream -> records partitioned by the top b1 bits of the hash ---------------
-__global__ void __launch_bounds__(PART_THREADS)
+// Thread t of a tile owns the 8 consecutive positions base + 8t .. 8t+7: two bases words and two
+// mask words (prefetched from HBM one tile ahead, straight to registers) cover all 8 windows,
+// which are produced by shifting one 128-bit register pair; the reverse complement rolls.
+template <int THREADS, int PER_THREAD, int MIN_WAVES>
+__global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t cap,
                  uint64_t *__restrict__ out, uint32_t *cursor, int cursor_stride, uint32_t n_tiles,
                  Counters *ctr)
 {
-    __shared__ SplitLds L;
-    __shared__ uint64_t wb[PART_TILE / 32 + 4];
-    __shared__ uint64_t wm[PART_TILE / 64 + 4];
+    constexpr int TILE = THREADS * PER_THREAD;
+    static_assert(PER_THREAD % 8 == 0 && PER_THREAD <= 16, "a thread's positions must stay inside two bases words");
+    __shared__ SplitLds<THREADS, PER_THREAD> L;
     const int tid = (int)threadIdx.x;
     const int nbins = 1 << b1;
     const int shift = 64 - b1;
     auto bin_of = [=](uint64_t h) -> uint32_t { return b1 ? (uint32_t)(h >> shift) : 0u; };
     uint32_t n_records = 0, n_overflow = 0;
+    for (int i = tid; i < nbins; i += THREADS) L.cnt[i] = 0;
+    __syncthreads();
+
+    const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
+    auto load_words = [&](uint32_t tile, uint64_t &w0, uint64_t &w1, uint64_t &m0, uint64_t &m1) {
+        const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
+        const uint64_t bw = p0 >> 5, mw = p0 >> 6;
+        w0 = s.bases[bw < last_b ? bw : last_b];
+        w1 = s.bases[bw + 1 < last_b ? bw + 1 : last_b];
+        m0 = s.mask[mw < last_m ? mw : last_m];
+        m1 = s.mask[mw + 1 < last_m ? mw + 1 : last_m];
+    };
+    const int sk = 64 - 2 * k;
+    const uint64_t kmask_shift = 64 - k;
+    uint64_t nw0 = 0, nw1 = 0, nm0 = 0, nm1 = 0;
+    if (blockIdx.x < n_tiles) load_words(blockIdx.x, nw0, nw1, nm0, nm1);
 
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t base = (uint64_t)tile * PART_TILE;
-        const uint64_t bw0 = base >> 5, mw0 = base >> 6;
-        for (int i = tid; i < PART_TILE / 32 + 4; i += PART_THREADS) {
-            const uint64_t w = bw0 + i;
-            wb[i] = s.bases[w < s.n_bwords ? w : s.n_bwords - 1];
-        }
-        for (int i = tid; i < PART_TILE / 64 + 4; i += PART_THREADS) {
-            const uint64_t w = mw0 + i;
-            wm[i] = s.mask[w < s.n_mwords ? w : s.n_mwords - 1];
-        }
-        for (int i = tid; i < nbins; i += PART_THREADS) L.cnt[i] = 0;
-        __syncthreads();
+        const uint64_t w0 = nw0, w1 = nw1, m0 = nm0, m1 = nm1;
+        if (tile + gridDim.x < n_tiles) load_words(tile + gridDim.x, nw0, nw1, nm0, nm1);
+        const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
+        // left-align the stream at p0: 64 bases in (vh, vl), 64 flags in mv
+        const int o = 2 * (int)(p0 & 31);                 // PER_THREAD 8: 0,16,32,48; 16: 0,32
+        const uint64_t vh = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
+        const uint64_t vl = o ? (w1 << o) : w1;
+        const int ms = (int)(p0 & 63);
+        const uint64_t mv = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
 
-        auto W = [&](uint64_t i) -> uint64_t { return wb[i - bw0]; };
-        auto M = [&](uint64_t i) -> uint64_t { return wm[i - mw0]; };
-        uint64_t hs[PART_PER_THREAD];
-        uint32_t rk[PART_PER_THREAD];
+        uint64_t hs[PER_THREAD];
+        uint32_t rk[PER_THREAD];
+        uint64_t rc = 0;
 #pragma unroll
-        for (int j = 0; j < PART_PER_THREAD; j++) {
-            const uint64_t p = base + (uint64_t)j * PART_THREADS + tid;
-            Kmer km;
+        for (int j = 0; j < PER_THREAD; j++) {
+            const uint64_t win = j ? (vh << (2 * j)) | (vl >> (64 - 2 * j)) : vh;
+            const uint64_t fwd = win >> sk;
+            if (j == 0) rc = (~rev_pairs64(fwd)) >> sk;
+            else rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
+            const bool bad = ((mv << j) >> kmask_shift) != 0;
+            uint64_t km = fwd;
+            if (canonical && rc < fwd) km = rc;
             rk[j] = NO_RANK;
             hs[j] = 0;
-            if (p < s.n_bases && extract_kmer<false>(p, k, canonical, W, M, km)) {
-                hs[j] = fmix64(km.lo ^ seed);
+            if (!bad && p0 + j < s.n_bases) {
+                hs[j] = fmix64(km ^ seed);
                 rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
             }
         }
-        __syncthreads();
+        __syncthreads();                                 // A
         multisplit_flush(L, hs, rk, nbins, bin_of, cursor, cursor_stride, 0, cap, out, n_records, n_overflow);
     }
     if (tid == 0 && n_records) atomicAdd(&ctr->n_valid, (unsigned long long)n_records);
@@ -168,11 +223,11 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
 }
 
 // ---- level 2: records of coarse bin blockIdx.y -> segments by the next b2 bits --------------------
-__global__ void __launch_bounds__(PART_THREADS)
+__global__ void __launch_bounds__(PART_THREADS, 8)
 repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cursor1, uint32_t cap1,
               int b1, int b2, uint32_t cap2, uint64_t *__restrict__ out, uint32_t *cursor2, Counters *ctr)
 {
-    __shared__ SplitLds L;
+    __shared__ SplitLds<PART_THREADS, PART_PER_THREAD> L;
     const int tid = (int)threadIdx.x;
     const uint32_t c = blockIdx.y;
     uint32_t n = cursor1[(uint64_t)c * CURSOR_STRIDE];
@@ -190,14 +245,15 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ curs
 #pragma unroll
     for (int j = 0; j < PART_PER_THREAD; j++) {
         const uint32_t i = t0 + (uint32_t)j * PART_THREADS + tid;
-        rk[j] = NO_RANK;
-        hs[j] = 0;
-        if (i < n) {
-            hs[j] = src[i];
-            rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
-        }
+        hs[j] = i < n ? src[i] : 0;
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PART_PER_THREAD; j++) {
+        const uint32_t i = t0 + (uint32_t)j * PART_THREADS + tid;
+        rk[j] = NO_RANK;
+        if (i < n) rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+    }
+    __syncthreads();                                     // A
     uint32_t n_records = 0, n_overflow = 0;
     multisplit_flush(L, hs, rk, nbins, bin_of, cursor2 + ((uint64_t)c << b2), 1, (uint64_t)c << b2, cap2, out,
                      n_records, n_overflow);
@@ -424,20 +480,31 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     sv.n_bases = r->n_bases;
     sv.n_bwords = (r->n_bases + 31) / 32;
     sv.n_mwords = (r->n_bases + 63) / 64;
-    const uint64_t n_tiles = (r->n_bases + PART_TILE - 1) / PART_TILE;
+    // scan_part variants (threads x positions per thread, min waves/SIMD); DK_SCAN_VARIANT picks one
+    static const int variant = [] { const char *v = getenv("DK_SCAN_VARIANT"); return v ? atoi(v) : 2; }();
+    const int tile = variant == 2 ? 512 * 16 : variant == 3 ? 512 * 8 : 1024 * 8;
+    const int blocks_per_cu = variant == 1 ? 1 : variant == 3 ? 4 : 2;
+    const uint64_t n_tiles = (r->n_bases + tile - 1) / tile;
     if (n_tiles > 0xFFFFFFFFULL) return fail(e, DK_ERR_UNSUPPORTED, "batch too large for one bucketed pass");
-    const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * 2);
-    if (p.b2 == 0) {
-        scan_part_kernel<<<grid, PART_THREADS, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed,
-                                                               p.b1, p.cap2, B.b, B.cursor2, 1, (uint32_t)n_tiles, e->d_ctr);
-        DK_HIP(e, hipGetLastError());
-        stage_mark(e, "scan_part");
-    } else {
-        scan_part_kernel<<<grid, PART_THREADS, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed,
-                                                               p.b1, p.cap1, B.a, B.cursor1, CURSOR_STRIDE,
-                                                               (uint32_t)n_tiles, e->d_ctr);
-        DK_HIP(e, hipGetLastError());
-        stage_mark(e, "scan_part");
+    const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * blocks_per_cu);
+    const bool two = p.b2 != 0;
+    uint64_t *dst = two ? B.a : B.b;
+    uint32_t *cur = two ? B.cursor1 : B.cursor2;
+    const int stride = two ? CURSOR_STRIDE : 1;
+    const uint32_t cap = two ? p.cap1 : p.cap2;
+#define DK_SCAN_LAUNCH(T, P, W)                                                                              \
+    scan_part_kernel<T, P, W><<<grid, T, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
+                                                         p.b1, cap, dst, cur, stride, (uint32_t)n_tiles, e->d_ctr)
+    switch (variant) {
+    case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
+    case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
+    case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
+    default: DK_SCAN_LAUNCH(1024, 8, 8); break;
+    }
+#undef DK_SCAN_LAUNCH
+    DK_HIP(e, hipGetLastError());
+    stage_mark(e, "scan_part");
+    if (two) {
         const dim3 g2((p.cap1 + PART_TILE - 1) / PART_TILE, p.p1);
         repart_kernel<<<g2, PART_THREADS, 0, e->stream>>>(B.a, B.cursor1, p.cap1, p.b1, p.b2, p.cap2, B.b, B.cursor2, e->d_ctr);
         DK_HIP(e, hipGetLastError());

@@ -47,7 +47,9 @@ def assert_family_ran(eng):
     if not names:
         return
     if eng.mode == "bucketed":
-        assert "overflow_redo" not in names and names[0] == "scan_part", names
+        assert names[0] == "scan_part", names
+        if eng.k >= 12:      # tiny k: a handful of distinct k-mers, bins legitimately overflow and are redone
+            assert "overflow_redo" not in names, names
     elif eng.mode == "direct":
         assert names[0] in ("insert_direct", "probe_direct"), names
 
