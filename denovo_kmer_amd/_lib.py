@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdenovo_kmer.so")
+# DK_LIB_PATH: load another build of the same library (e.g. the DK_STAMPS diagnostic build)
+LIB_PATH = os.environ.get("DK_LIB_PATH") or os.path.join(_HERE, "libdenovo_kmer.so")
 
 DK_OK = 0
 DK_ERR_INVALID_ARG = 1

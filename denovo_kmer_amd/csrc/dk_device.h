@@ -139,6 +139,26 @@ __device__ __forceinline__ uint64_t wave_append(bool pred, unsigned long long *c
     return base + (uint64_t)popc_below(b);
 }
 
+// Inclusive prefix sum across the 64 lanes of a wave with DPP row shifts / broadcasts: pure VALU,
+// no LDS crossbar traffic (__shfl_* lowers to ds_bpermute, whose latency balloons when the LDS is
+// busy, which is exactly when the multisplit kernels scan their bin counts).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// sum over the wave, returned to every lane (scalar broadcast of lane 63 of the scan)
+__device__ __forceinline__ uint32_t wave_total(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
+}
+
 __device__ __forceinline__ uint64_t wave_sum(uint64_t v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);

@@ -38,13 +38,52 @@ constexpr int CNT_THREADS = 256;
 constexpr int CNT_SLOTS = 4096;                        // LDS hash table of seg_count
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
+constexpr int MAX_R = 4;                               // level-2 producer groups per coarse bin
+
+// Buckets are built from PRIVATE pieces, so the partition needs no global atomics at all:
+//   level 1: workgroup w of scan_part owns piece (bin b, w) = a[(b*G + w) * capw ...]
+//   level 2: workgroup (b, r) of repart reads the pieces (b, w) of its share of the producers and
+//            owns piece (segment s, r) = b[(s*R + r) * capr ...]
+// Running cursors live in LDS for the life of the workgroup; piece sizes are stored once at the end.
 struct BucketPlan {
     int T;                 // log2(number of segments)
-    int b1, b2;            // bits split at level 1 / level 2 (b2 == 0: single level)
+    int b1, b2;            // hash bits consumed at level 1 / level 2 (b1 + b2 = T, b2 >= 1)
     uint32_t p1, p2;       // bins at each level
     uint64_t n_seg;
-    uint32_t cap1, cap2;   // records per level-1 bin / per segment
+    uint32_t G;            // scan_part workgroups = level-1 pieces per bin
+    uint32_t R;            // level-2 pieces per segment
+    uint32_t capw, capr;   // records per level-1 piece / level-2 piece
     uint64_t n_max;        // upper bound on records of the batch
+    int tile;              // positions per scan_part tile
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load and store of the wave (s_waitcnt vmcnt(0)), which would serialise the prefetch of the
+// next tile and the copy-out stores of the previous one behind each barrier; the partition kernels
+// exchange data through LDS only, so lgkmcnt(0) + s_barrier is the required ordering.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// DK_STAMPS diagnostic build: thread 0 of each workgroup sums the cycles between phase marks and
+// adds them to Counters::dbg at the end (never enabled in the shipped library)
+struct Stamps {
+#ifdef DK_STAMPS
+    unsigned long long prev, acc[4];
+    __device__ __forceinline__ Stamps() : prev(clock64()), acc{0, 0, 0, 0} {}
+    __device__ __forceinline__ void mark(int i)
+    {
+        if (threadIdx.x == 0) { const unsigned long long t = clock64(); acc[i] += t - prev; prev = t; }
+    }
+    __device__ __forceinline__ void flush(Counters *ctr, int base)
+    {
+        if (threadIdx.x == 0) for (int i = 0; i < 4; i++) atomicAdd(&ctr->dbg[base + i], acc[i]);
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(Counters *, int) {}
+#endif
 };
 
 // exclusive prefix sum over the block; every thread calls it; *total gets the block sum
@@ -53,20 +92,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int n_waves = (int)(blockDim.x >> 6);
-    uint32_t inc = v;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o);
-        if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
     if (wave == 0) {
-        uint32_t w = lane < n_waves ? wave_sums[lane] : 0;
-        uint32_t wi = w;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(wi, o);
-            if (lane >= o) wi += t;
-        }
+        const uint32_t w = lane < n_waves ? wave_sums[lane] : 0;
+        const uint32_t wi = wave_incl_scan(w);
         if (lane < n_waves) wave_sums[lane] = wi - w;       // exclusive wave offsets
         if (lane == n_waves - 1) *total = wi;
     }
@@ -76,88 +107,106 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
 
 // ---- shared multisplit tail ------------------------------------------------------------------------
 // A tile's records sit in registers (hs = hash, rk = rank inside its bin from the LDS count).
-// Wave 0 turns the per-bin counts into tile offsets and reserves the global ranges; the global
-// atomics stay in flight while every wave scatters its records into the LDS stage, and only the
-// copy-out needs their result.  Three barriers per tile (A: counts done - by the caller,
-// B: offsets ready, C: stage + global bases ready); the next tile's count phase needs no barrier
-// because it touches only cnt[], which wave 0 re-zeroes before B.
+// Wave 0 turns the per-bin counts into tile offsets and advances the workgroup's running cursors
+// (all in LDS); every wave then scatters its records into the LDS stage and the stage is copied
+// out as per-bin runs.  Three barriers per tile (A: counts done - by the caller, B: offsets ready,
+// C: stage ready); the next tile's count phase needs no barrier because it touches only cnt[],
+// which wave 0 re-zeroes before B.
 template <int THREADS, int PER_THREAD>
 struct SplitLds {
     uint64_t stage[THREADS * PER_THREAD];
-    uint32_t cnt[MAX_BINS];     // must be zero on entry to the first tile
-    uint32_t off[MAX_BINS];
-    uint32_t delta[MAX_BINS];   // global index in bin = stage index + delta[bin]  (mod 2^32)
+    uint32_t cnt[MAX_BINS];     // per-tile counts; zero on entry to every count phase
+    uint32_t off[MAX_BINS];     // tile offset of each bin in stage[]
+    uint32_t delta[MAX_BINS];   // index in the piece = stage index + delta[bin]  (mod 2^32)
+    uint32_t cur[MAX_BINS];     // running fill of this workgroup's piece of each bin
     uint32_t total;
 };
 
-constexpr int MAX_BINS_PER_LANE = MAX_BINS / 64;
 
+template <int THREADS, int PER_THREAD>
+__device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD> &L, int nbins)
+{
+    for (int i = (int)threadIdx.x; i < MAX_BINS; i += THREADS) { L.cnt[i] = 0; L.cur[i] = 0; }
+    __syncthreads();
+}
+
+// out index of record idx of bin: (bin_base + bin) * bin_stride + piece_off + idx.
+// `valid` has bit j set when hs[j] holds a record (already counted into L.cnt by the caller).
 template <int THREADS, int PER_THREAD, class BinOf>
 __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &L, const uint64_t (&hs)[PER_THREAD],
-                                                 const uint32_t (&rk)[PER_THREAD], int nbins, BinOf bin_of,
-                                                 uint32_t *cursor, int cursor_stride, uint64_t bin_base,
+                                                 uint32_t valid, int nbins, BinOf bin_of,
+                                                 uint64_t bin_base, uint64_t bin_stride, uint64_t piece_off,
                                                  uint32_t cap, uint64_t *__restrict__ out,
-                                                 uint32_t &n_records, uint32_t &n_overflow)
+                                                 uint32_t &n_records, uint32_t &n_overflow, Stamps &st)
 {
     const int tid = (int)threadIdx.x;
-    const bool w0 = tid < 64;
-    const int m = nbins > 64 ? nbins / 64 : 1;          // bins per lane of wave 0
-    const int first = tid * m;
-    uint32_t g[MAX_BINS_PER_LANE];                      // the only state wave 0 carries across barrier B
-    if (w0) {
-        uint32_t sum = 0;
+    st.mark(0);
+    // Parallel scan of the bin counts: lane = bin.  Each scanning wave sums the counts of the waves
+    // below it itself (independent LDS reads, one wave reduction), so no wave waits for another and
+    // the dependent LDS chain is one read deep.
+    const int wv = tid >> 6, lane = tid & 63;
+    if (wv * 64 < nbins) {
+        const uint32_t c = tid < nbins ? L.cnt[tid] : 0;
+        const uint32_t cu = tid < nbins ? L.cur[tid] : 0;
+        uint32_t below = 0;
 #pragma unroll
-        for (int q = 0; q < MAX_BINS_PER_LANE; q++) {
-            if (q < m && first + q < nbins) { L.off[first + q] = sum; sum += L.cnt[first + q]; }
+        for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
+            const uint32_t x = L.cnt[64 * v + lane];    // unconditional: the reads pipeline (cnt[] is zero beyond nbins)
+            below += v < wv ? x : 0u;
         }
-        uint32_t inc = sum;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o);
-            if (tid >= o) inc += t;
-        }
-        const uint32_t lane_base = inc - sum;
-        if (tid == 63) L.total = inc;
-#pragma unroll
-        for (int q = 0; q < MAX_BINS_PER_LANE; q++) {
-            g[q] = 0;
-            if (q < m && first + q < nbins) {
-                const uint32_t c = L.cnt[first + q];
-                L.cnt[first + q] = 0;
-                L.off[first + q] += lane_base;
-                if (c) g[q] = atomicAdd(&cursor[(uint64_t)(first + q) * cursor_stride], c);
-            }
+        below = wave_total(below);
+        const uint32_t inc = wave_incl_scan(c);
+        const uint32_t ex = below + inc - c;
+        if (tid < nbins) {
+            L.off[tid] = ex;
+            L.delta[tid] = cu - ex;
+            L.cur[tid] = cu + c;
+            if (tid == nbins - 1) L.total = ex + c;
         }
     }
-    __syncthreads();                                     // B
+    lds_barrier();                                       // B
+    st.mark(1);
+    if (tid < nbins) L.cnt[tid] = 0;                     // every scanning wave has read it
+    // off[bin] now serves as the running slot counter of the bin inside the stage
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++)
-        if (rk[j] != NO_RANK) L.stage[L.off[bin_of(hs[j])] + rk[j]] = hs[j];
-    if (w0) {
-#pragma unroll
-        for (int q = 0; q < MAX_BINS_PER_LANE; q++)
-            if (q < m && first + q < nbins) L.delta[first + q] = g[q] - L.off[first + q];
-    }
-    __syncthreads();                                     // C
+        if ((valid >> j) & 1u) L.stage[atomicAdd(&L.off[bin_of(hs[j])], 1u)] = hs[j];
+    lds_barrier();                                       // C
+    st.mark(2);
     const uint32_t total = L.total;
+#pragma unroll 8
     for (uint32_t i = tid; i < total; i += THREADS) {
         const uint64_t h = L.stage[i];
         const uint32_t bin = bin_of(h);
         const uint32_t idx = i + L.delta[bin];
-        if (idx < cap) out[(bin_base + bin) * cap + idx] = h;
+        if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = h;
         else n_overflow++;
     }
     if (tid == 0) n_records += total;
+    st.mark(3);
+}
+
+// piece sizes, once per workgroup: cnt_out[(bin_base + bin) * n_pieces + piece] = min(fill, cap)
+template <int THREADS, int PER_THREAD>
+__device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD> &L, int nbins, uint64_t bin_base,
+                                                  uint32_t n_pieces, uint32_t piece, uint32_t cap,
+                                                  uint32_t *__restrict__ cnt_out)
+{
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < nbins; i += THREADS) {
+        const uint32_t c = L.cur[i];
+        cnt_out[(bin_base + i) * n_pieces + piece] = c < cap ? c : cap;
+    }
 }
 
 // ---- level 1: packed stream -> records partitioned by the top b1 bits of the hash ---------------
-// Thread t of a tile owns the 8 consecutive positions base + 8t .. 8t+7: two bases words and two
-// mask words (prefetched from HBM one tile ahead, straight to registers) cover all 8 windows,
-// which are produced by shifting one 128-bit register pair; the reverse complement rolls.
+// Thread t of a tile owns PER_THREAD consecutive positions: two bases words and two mask words
+// (prefetched from HBM one tile ahead, straight to registers) cover all its windows, which are
+// produced by shifting one 128-bit register pair; the reverse complement rolls.
 template <int THREADS, int PER_THREAD, int MIN_WAVES>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
-scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t cap,
-                 uint64_t *__restrict__ out, uint32_t *cursor, int cursor_stride, uint32_t n_tiles,
-                 Counters *ctr)
+scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
+                 uint64_t *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles, Counters *ctr)
 {
     constexpr int TILE = THREADS * PER_THREAD;
     static_assert(PER_THREAD % 8 == 0 && PER_THREAD <= 16, "a thread's positions must stay inside two bases words");
@@ -167,8 +216,8 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     const int shift = 64 - b1;
     auto bin_of = [=](uint64_t h) -> uint32_t { return b1 ? (uint32_t)(h >> shift) : 0u; };
     uint32_t n_records = 0, n_overflow = 0;
-    for (int i = tid; i < nbins; i += THREADS) L.cnt[i] = 0;
-    __syncthreads();
+    multisplit_init(L, nbins);
+    Stamps st;
 
     const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
     auto load_words = [&](uint32_t tile, uint64_t &w0, uint64_t &w1, uint64_t &m0, uint64_t &m1) {
@@ -181,9 +230,11 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     };
     const int sk = 64 - 2 * k;
     const uint64_t kmask_shift = 64 - k;
+    const uint64_t G = gridDim.x, w = blockIdx.x;
     uint64_t nw0 = 0, nw1 = 0, nm0 = 0, nm1 = 0;
     if (blockIdx.x < n_tiles) load_words(blockIdx.x, nw0, nw1, nm0, nm1);
 
+#pragma unroll 1
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t w0 = nw0, w1 = nw1, m0 = nm0, m1 = nm1;
         if (tile + gridDim.x < n_tiles) load_words(tile + gridDim.x, nw0, nw1, nm0, nm1);
@@ -196,7 +247,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         const uint64_t mv = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
 
         uint64_t hs[PER_THREAD];
-        uint32_t rk[PER_THREAD];
+        uint32_t valid = 0;
         uint64_t rc = 0;
 #pragma unroll
         for (int j = 0; j < PER_THREAD; j++) {
@@ -207,61 +258,137 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             const bool bad = ((mv << j) >> kmask_shift) != 0;
             uint64_t km = fwd;
             if (canonical && rc < fwd) km = rc;
-            rk[j] = NO_RANK;
-            hs[j] = 0;
+            hs[j] = fmix64(km ^ seed);
             if (!bad && p0 + j < s.n_bases) {
-                hs[j] = fmix64(km ^ seed);
-                rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+                valid |= 1u << j;
+                atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
             }
+            // keep the windows sequential: interleaving the eight hash chains costs ~40 VGPRs and
+            // with them half the resident waves, which hide latency better than in-wave ILP does
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                 // A
-        multisplit_flush(L, hs, rk, nbins, bin_of, cursor, cursor_stride, 0, cap, out, n_records, n_overflow);
+        lds_barrier();                                   // A
+        multisplit_flush(L, hs, valid, nbins, bin_of, 0, G * capw, w * capw, capw, out, n_records, n_overflow, st);
     }
+    st.flush(ctr, 0);
+    multisplit_finish(L, nbins, 0, (uint32_t)G, (uint32_t)w, capw, cnt1);
     if (tid == 0 && n_records) atomicAdd(&ctr->n_valid, (unsigned long long)n_records);
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
 }
 
-// ---- level 2: records of coarse bin blockIdx.y -> segments by the next b2 bits --------------------
-__global__ void __launch_bounds__(PART_THREADS, 8)
-repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cursor1, uint32_t cap1,
-              int b1, int b2, uint32_t cap2, uint64_t *__restrict__ out, uint32_t *cursor2, Counters *ctr)
+// ---- level 2: workgroup (r = blockIdx.x, b = blockIdx.y) re-splits its share of the level-1 pieces
+// of coarse bin b by the next b2 hash bits into its own piece r of each of the bin's segments -------
+template <int THREADS, int PER_THREAD, int MIN_WAVES>
+__global__ void __launch_bounds__(THREADS, MIN_WAVES)
+repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
+              int b1, int b2, uint32_t R, uint32_t capr, uint64_t *__restrict__ out,
+              uint32_t *__restrict__ cnt2, Counters *ctr)
 {
-    __shared__ SplitLds<PART_THREADS, PART_PER_THREAD> L;
+    __shared__ SplitLds<THREADS, PER_THREAD> L;
+    constexpr int TILE = THREADS * PER_THREAD;
     const int tid = (int)threadIdx.x;
-    const uint32_t c = blockIdx.y;
-    uint32_t n = cursor1[(uint64_t)c * CURSOR_STRIDE];
-    if (n > cap1) n = cap1;
-    const uint32_t t0 = blockIdx.x * PART_TILE;
-    if (t0 >= n) return;
+    const uint32_t b = blockIdx.y, r = blockIdx.x;
     const int nbins = 1 << b2;
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
-    for (int i = tid; i < nbins; i += PART_THREADS) L.cnt[i] = 0;
-    __syncthreads();
-    const uint64_t *src = in + (uint64_t)c * cap1;
-    uint64_t hs[PART_PER_THREAD];
-    uint32_t rk[PART_PER_THREAD];
-#pragma unroll
-    for (int j = 0; j < PART_PER_THREAD; j++) {
-        const uint32_t i = t0 + (uint32_t)j * PART_THREADS + tid;
-        hs[j] = i < n ? src[i] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < PART_PER_THREAD; j++) {
-        const uint32_t i = t0 + (uint32_t)j * PART_THREADS + tid;
-        rk[j] = NO_RANK;
-        if (i < n) rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
-    }
-    __syncthreads();                                     // A
+    multisplit_init(L, nbins);
+    Stamps st;
+    const uint32_t per = (G + R - 1) / R;
+    const uint32_t w_lo = r * per, w_hi = (w_lo + per < G) ? w_lo + per : G;
     uint32_t n_records = 0, n_overflow = 0;
-    multisplit_flush(L, hs, rk, nbins, bin_of, cursor2 + ((uint64_t)c << b2), 1, (uint64_t)c << b2, cap2, out,
-                     n_records, n_overflow);
+    const uint32_t *pcnt = cnt1 + (uint64_t)b * G;
+    const uint64_t *pin = in + (uint64_t)b * G * capw;
+    auto piece_size = [&](uint32_t w) -> uint32_t { const uint32_t c = pcnt[w]; return c < capw ? c : capw; };
+    auto load_tile = [&](uint32_t w, uint32_t t0, uint32_t n, uint64_t (&h)[PER_THREAD]) {
+        const uint64_t *src = pin + (uint64_t)w * capw;
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; j++) {
+            const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+            h[j] = i < n ? src[i] : 0;
+        }
+    };
+    // walk the (piece, tile) sequence with the next tile's records already in flight
+    uint32_t w = w_lo, t0 = 0, n = 0;
+    while (w < w_hi && (n = piece_size(w)) == 0) w++;
+    uint64_t hs[PER_THREAD], nx[PER_THREAD];
+    if (w < w_hi) load_tile(w, 0, n, hs);
+#pragma unroll 1
+    while (w < w_hi) {
+        uint32_t nw = w, nt0 = t0 + TILE, nn = n;
+        if (nt0 >= nn) {
+            nt0 = 0;
+            nw++;
+            while (nw < w_hi && (nn = piece_size(nw)) == 0) nw++;
+        }
+        if (nw < w_hi) load_tile(nw, nt0, nn, nx);
+        uint32_t valid = 0;
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; j++) {
+            const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+            if (i < n) {
+                valid |= 1u << j;
+                atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+            }
+        }
+        lds_barrier();                                   // A
+        multisplit_flush(L, hs, valid, nbins, bin_of, (uint64_t)b << b2, (uint64_t)R * capr, (uint64_t)r * capr,
+                         capr, out, n_records, n_overflow, st);
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; j++) hs[j] = nx[j];
+        w = nw;
+        t0 = nt0;
+        n = nn;
+    }
+    st.flush(ctr, 4);
+    multisplit_finish(L, nbins, (uint64_t)b << b2, R, r, capr, cnt2);
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
 }
 
 // ---- per-segment kernels ----------------------------------------------------------------------------
+// A segment's records are the concatenation of n_pieces pieces:
+//   piece r of segment s = recs[(s * n_pieces + r) * piece_cap ...], cnt[s * n_pieces + r] records
+struct PieceList {
+    const uint64_t *recs;
+    const uint32_t *cnt;
+    uint32_t n_pieces;     // <= MAX_R
+    uint32_t piece_cap;
+};
+
+struct SegPieces {
+    uint32_t start[MAX_R + 1];     // prefix sums of the piece sizes; start[n_pieces] = total
+    const uint64_t *base;          // first piece of the segment
+    uint32_t piece_cap;
+    __device__ __forceinline__ uint32_t total() const { return start[MAX_R]; }
+    __device__ __forceinline__ uint64_t at(uint32_t i) const
+    {
+        uint32_t r = 0, st = 0;
+#pragma unroll
+        for (int q = 1; q < MAX_R; q++)
+            if (i >= start[q]) { r = (uint32_t)q; st = start[q]; }     // starts are non-decreasing
+        return base[(uint64_t)r * piece_cap + (i - st)];
+    }
+};
+
+__device__ __forceinline__ SegPieces seg_pieces(const PieceList &pl, uint64_t seg_id)
+{
+    SegPieces sp;
+    sp.base = pl.recs + seg_id * pl.n_pieces * (uint64_t)pl.piece_cap;
+    sp.piece_cap = pl.piece_cap;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < MAX_R; q++) {
+        sp.start[q] = acc;
+        if ((uint32_t)q < pl.n_pieces) {
+            uint32_t c = pl.cnt[seg_id * pl.n_pieces + q];
+            acc += c < pl.piece_cap ? c : pl.piece_cap;
+        }
+    }
+    sp.start[MAX_R] = acc;
+    return sp;
+}
+
 __device__ __forceinline__ void load_segment(uint32_t *seg, const unsigned long long *filter, uint64_t seg_id)
 {
     const uint4 *src = (const uint4 *)filter + seg_id * (SEG_BYTES / 16);
@@ -270,19 +397,17 @@ __device__ __forceinline__ void load_segment(uint32_t *seg, const unsigned long 
 }
 
 __global__ void __launch_bounds__(SEG_THREADS)
-seg_insert_kernel(unsigned long long *filter, const uint64_t *__restrict__ recs,
-                  const uint32_t *__restrict__ cursor2, uint32_t cap2, int n_hashes, int blk_shift)
+seg_insert_kernel(unsigned long long *filter, PieceList pl, int n_hashes, int blk_shift)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
     const uint64_t seg_id = blockIdx.x;
-    uint32_t n = cursor2[seg_id];
+    const SegPieces sp = seg_pieces(pl, seg_id);
+    const uint32_t n = sp.total();
     if (n == 0) return;                       // nothing to add: leave the segment untouched
-    if (n > cap2) n = cap2;
     load_segment(seg, filter, seg_id);
     __syncthreads();
-    const uint64_t *src = recs + seg_id * cap2;
     for (uint32_t i = threadIdx.x; i < n; i += SEG_THREADS) {
-        const uint64_t h = src[i];
+        const uint64_t h = sp.at(i);
         const uint32_t blk = (uint32_t)(h >> blk_shift) & (SEG_BLOCKS - 1);
         const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
         for (int j = 0; j < n_hashes; j++) {
@@ -296,17 +421,16 @@ seg_insert_kernel(unsigned long long *filter, const uint64_t *__restrict__ recs,
     for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += SEG_THREADS) dst[i] = s4[i];
 }
 
-// absent records of segment s are written to miss[s * cap2 ...], their number to miss_cnt[s]
+// absent records of segment s are written to miss[s * miss_cap ...], their number to miss_cnt[s]
 __global__ void __launch_bounds__(SEG_THREADS)
-seg_probe_kernel(const unsigned long long *__restrict__ filter, const uint64_t *__restrict__ recs,
-                 const uint32_t *__restrict__ cursor2, uint32_t cap2, int n_hashes, int blk_shift,
-                 uint64_t *__restrict__ miss, uint32_t *__restrict__ miss_cnt, Counters *ctr)
+seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, int n_hashes, int blk_shift,
+                 uint64_t *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
     __shared__ uint32_t n_miss;
     const uint64_t seg_id = blockIdx.x;
-    uint32_t n = cursor2[seg_id];
-    if (n > cap2) n = cap2;
+    const SegPieces sp = seg_pieces(pl, seg_id);
+    const uint32_t n = sp.total();
     if (n == 0) {
         if (threadIdx.x == 0) miss_cnt[seg_id] = 0;
         return;
@@ -314,12 +438,11 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, const uint64_t *
     if (threadIdx.x == 0) n_miss = 0;
     load_segment(seg, filter, seg_id);
     __syncthreads();
-    const uint64_t *src = recs + seg_id * cap2;
-    uint64_t *dst = miss + seg_id * cap2;
+    uint64_t *dst = miss + seg_id * miss_cap;
     const uint32_t n_round = (n + 63) & ~63u;
     for (uint32_t i = threadIdx.x; i < n_round; i += SEG_THREADS) {
         const bool have = i < n;
-        const uint64_t h = have ? src[i] : 0;
+        const uint64_t h = have ? sp.at(i) : 0;
         const uint32_t blk = (uint32_t)(h >> blk_shift) & (SEG_BLOCKS - 1);
         const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
         bool all = true;
@@ -346,8 +469,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, const uint64_t *
 
 // exact counting of one segment's absent records in an LDS hash table, `rounds` sub-ranges at a time
 __global__ void __launch_bounds__(CNT_THREADS)
-seg_count_kernel(const uint64_t *__restrict__ list, const uint32_t *__restrict__ list_cnt, uint32_t cap2,
-                 int T, uint64_t seed, uint32_t min_count, uint64_t out_cap,
+seg_count_kernel(PieceList pl, int T, uint64_t seed, uint32_t min_count, uint64_t out_cap,
                  uint64_t *__restrict__ out_kmer, uint32_t *__restrict__ out_cnt, Counters *ctr)
 {
     __shared__ unsigned long long keys[CNT_SLOTS];
@@ -356,10 +478,9 @@ seg_count_kernel(const uint64_t *__restrict__ list, const uint32_t *__restrict__
     __shared__ uint32_t total;
     __shared__ unsigned long long gbase;
     const uint64_t seg_id = blockIdx.x;
-    uint32_t n = list_cnt[seg_id];
-    if (n > cap2) n = cap2;
+    const SegPieces sp = seg_pieces(pl, seg_id);
+    const uint32_t n = sp.total();
     if (n == 0) return;
-    const uint64_t *src = list + seg_id * cap2;
     // a value no record of this segment can take: its top T bits differ from the segment id
     const unsigned long long EMPTY = (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
     const uint32_t rounds = (n + CNT_SLOTS / 2 - 1) / (CNT_SLOTS / 2);
@@ -368,7 +489,7 @@ seg_count_kernel(const uint64_t *__restrict__ list, const uint32_t *__restrict__
         for (int i = (int)threadIdx.x; i < CNT_SLOTS; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += CNT_THREADS) {
-            const uint64_t h = src[i];
+            const uint64_t h = sp.at(i);
             const uint32_t rr = (uint32_t)((((h >> 33) & 0x1FFF) * rounds) >> 13);
             if (rr != r) continue;
             uint32_t slot = (uint32_t)(h >> 20) & (CNT_SLOTS - 1);
@@ -410,14 +531,22 @@ seg_count_kernel(const uint64_t *__restrict__ list, const uint32_t *__restrict__
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
-// Records per bin are not Poisson: a k-mer seen m times (coverage, repeats) puts all m copies in
-// one bin, so the variance is mean * E[m^2]/E[m].  The slack covers 8 sigma for a multiplicity
-// ratio of 64 (30-60x coverage); anything heavier (poly-A style heavy hitters) overflows and is
-// handled exactly by the direct family.
-inline uint32_t bin_capacity(double mean)
+// Piece capacity = mean + 8 sigma.  Records per piece are not Poisson: a k-mer seen m times
+// (coverage, repeats) lands all its copies in one segment, so the variance is mean * ratio with
+// ratio = E[m^2]/E[m].  Level-1 pieces see 1/G of the reads, so copies of one k-mer rarely meet
+// there (ratio 4 allowed); level-2 pieces gather a whole segment (ratio 64 allowed, 30-60x
+// coverage).  Anything heavier (poly-A style heavy hitters) overflows, is detected, and the batch
+// is redone exactly by the direct family.
+inline uint32_t piece_capacity(double mean, double ratio)
 {
-    const double c = mean + 64.0 * sqrt(mean + 1.0) + 256.0;
+    const double c = mean + 8.0 * sqrt((mean + 1.0) * ratio) + 256.0;
     return (uint32_t)((uint64_t)(c + 1.0) + 1) & ~1u;
+}
+
+inline int scan_variant()
+{
+    static const int v = [] { const char *e = getenv("DK_SCAN_VARIANT"); return e ? atoi(e) : 2; }();
+    return v;
 }
 
 inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
@@ -425,16 +554,32 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
     if (e->cfg.k > 32) return false;
     p->T = (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
     if (p->T < 1 || p->T > 2 * MAX_BIN_BITS) return false;
-    if (p->T <= MAX_BIN_BITS) { p->b1 = p->T; p->b2 = 0; }
-    else { p->b1 = (p->T + 1) / 2; p->b2 = p->T - p->b1; }
+    static const int b1_up = [] { const char *v = getenv("DK_B1_UP"); return v ? atoi(v) : 0; }();
+    p->b1 = (p->T + b1_up) / 2;
+    if (p->b1 > MAX_BIN_BITS) p->b1 = MAX_BIN_BITS;
+    if (p->T - p->b1 > MAX_BIN_BITS) p->b1 = p->T - MAX_BIN_BITS;
+    p->b2 = p->T - p->b1;
     p->p1 = 1u << p->b1;
     p->p2 = 1u << p->b2;
     p->n_seg = 1ULL << p->T;
     p->n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
-    const double c1 = (double)p->n_max / p->p1, c2 = (double)p->n_max / (double)p->n_seg;
-    if (c1 + 64.0 * sqrt(c1 + 1.0) + 512.0 >= 4.0e9) return false;      // u32 cursors
-    p->cap1 = bin_capacity(c1);
-    p->cap2 = bin_capacity(c2);
+    const int v = scan_variant();
+    p->tile = v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : 1024 * 8;
+    const int blocks_per_cu = v == 1 ? 1 : v == 3 ? 4 : 2;
+    const uint64_t n_tiles = (r->n_bases + p->tile - 1) / p->tile;
+    if (n_tiles > 0xFFFFFFFFULL) return false;
+    p->G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), (uint64_t)e->n_cu * blocks_per_cu);
+    static const uint32_t r_env = [] { const char *v = getenv("DK_R"); return v ? (uint32_t)atoi(v) : 4u; }();
+    p->R = std::min<uint32_t>(std::min<uint32_t>(MAX_R, std::max<uint32_t>(r_env, 1)), p->G);
+    // expected piece sizes, from the largest share a producer can get (tiles and producer groups
+    // are dealt round-robin, so shares differ by at most one tile / one producer)
+    const uint64_t tiles_per_wg = (n_tiles + p->G - 1) / p->G;
+    const double share1 = (double)std::min<uint64_t>(p->n_max, tiles_per_wg * (uint64_t)p->tile);
+    const double m1 = share1 / (double)p->p1;
+    const double m2 = share1 * (double)((p->G + p->R - 1) / p->R) / (double)p->n_seg;
+    if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 piece cursors
+    p->capw = piece_capacity(m1, 4.0);
+    p->capr = piece_capacity(m2, std::max(4.0, 64.0 / p->R));    // copies of one k-mer spread over the R producer groups
     return true;
 }
 
@@ -448,31 +593,30 @@ inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases)
 }
 
 struct BucketBufs {
-    uint64_t *a = nullptr, *b = nullptr;      // level-1 bins (later: absent lists) / segment bins
-    uint32_t *cur = nullptr;                  // cursor1 [p1 * stride] | cursor2 [n_seg] | miss_cnt [n_seg]
-    uint32_t *cursor1 = nullptr, *cursor2 = nullptr, *miss_cnt = nullptr;
+    uint64_t *a = nullptr, *b = nullptr;      // level-1 pieces (later: absent lists) / segment pieces
+    uint32_t *cnt = nullptr;                  // cnt1 [p1 * G] | cnt2 [n_seg * R] | miss_cnt [n_seg]
+    uint32_t *cnt1 = nullptr, *cnt2 = nullptr, *miss_cnt = nullptr;
 };
 
 inline void free_bufs(dk_engine *e, BucketBufs &B)
 {
     pool_free(e, B.a);
     pool_free(e, B.b);
-    pool_free(e, B.cur);
+    pool_free(e, B.cnt);
 }
 
-// scan_part (+ repart): afterwards B.b holds every record of the batch grouped by segment
+// scan_part + repart: afterwards B.b / B.cnt2 hold every record of the batch grouped by segment
 inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p, BucketBufs &B)
 {
-    const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
-    const uint64_t lvl1_recs = p.b2 ? (uint64_t)p.p1 * p.cap1 : 0;
+    const uint64_t seg_recs = p.n_seg * (uint64_t)p.R * p.capr;
+    const uint64_t lvl1_recs = (uint64_t)p.p1 * p.G * p.capw;
     DK_TRY(pool_alloc(e, std::max(seg_recs, lvl1_recs) * 8, (void **)&B.a));
     DK_TRY(pool_alloc(e, seg_recs * 8, (void **)&B.b));
-    const uint64_t n_cur = (uint64_t)p.p1 * CURSOR_STRIDE + 2 * p.n_seg;
-    DK_TRY(pool_alloc(e, n_cur * 4, (void **)&B.cur));
-    B.cursor1 = B.cur;
-    B.cursor2 = B.cur + (uint64_t)p.p1 * CURSOR_STRIDE;
-    B.miss_cnt = B.cursor2 + p.n_seg;
-    DK_HIP(e, hipMemsetAsync(B.cur, 0, n_cur * 4, e->stream));
+    const uint64_t n1 = (uint64_t)p.p1 * p.G, n2 = p.n_seg * p.R;
+    DK_TRY(pool_alloc(e, (n1 + n2 + p.n_seg) * 4, (void **)&B.cnt));
+    B.cnt1 = B.cnt;
+    B.cnt2 = B.cnt + n1;
+    B.miss_cnt = B.cnt2 + n2;
 
     StreamView sv;
     sv.bases = r->d_bases;
@@ -480,22 +624,11 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     sv.n_bases = r->n_bases;
     sv.n_bwords = (r->n_bases + 31) / 32;
     sv.n_mwords = (r->n_bases + 63) / 64;
-    // scan_part variants (threads x positions per thread, min waves/SIMD); DK_SCAN_VARIANT picks one
-    static const int variant = [] { const char *v = getenv("DK_SCAN_VARIANT"); return v ? atoi(v) : 2; }();
-    const int tile = variant == 2 ? 512 * 16 : variant == 3 ? 512 * 8 : 1024 * 8;
-    const int blocks_per_cu = variant == 1 ? 1 : variant == 3 ? 4 : 2;
-    const uint64_t n_tiles = (r->n_bases + tile - 1) / tile;
-    if (n_tiles > 0xFFFFFFFFULL) return fail(e, DK_ERR_UNSUPPORTED, "batch too large for one bucketed pass");
-    const int grid = (int)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * blocks_per_cu);
-    const bool two = p.b2 != 0;
-    uint64_t *dst = two ? B.a : B.b;
-    uint32_t *cur = two ? B.cursor1 : B.cursor2;
-    const int stride = two ? CURSOR_STRIDE : 1;
-    const uint32_t cap = two ? p.cap1 : p.cap2;
-#define DK_SCAN_LAUNCH(T, P, W)                                                                              \
-    scan_part_kernel<T, P, W><<<grid, T, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
-                                                         p.b1, cap, dst, cur, stride, (uint32_t)n_tiles, e->d_ctr)
-    switch (variant) {
+    const uint32_t n_tiles = (uint32_t)((r->n_bases + p.tile - 1) / p.tile);
+#define DK_SCAN_LAUNCH(TH, PT, W)                                                                                  \
+    scan_part_kernel<TH, PT, W><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
+                                                           p.b1, p.capw, B.a, B.cnt1, n_tiles, e->d_ctr)
+    switch (scan_variant()) {
     case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
     case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
     case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
@@ -504,18 +637,34 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #undef DK_SCAN_LAUNCH
     DK_HIP(e, hipGetLastError());
     stage_mark(e, "scan_part");
-    if (two) {
-        const dim3 g2((p.cap1 + PART_TILE - 1) / PART_TILE, p.p1);
-        repart_kernel<<<g2, PART_THREADS, 0, e->stream>>>(B.a, B.cursor1, p.cap1, p.b1, p.b2, p.cap2, B.b, B.cursor2, e->d_ctr);
-        DK_HIP(e, hipGetLastError());
-        stage_mark(e, "repart");
+#define DK_REPART_LAUNCH(TH, PT, W)                                                                              \
+    repart_kernel<TH, PT, W><<<dim3(p.R, p.p1), TH, 0, e->stream>>>(B.a, B.cnt1, p.G, p.capw, p.b1, p.b2, p.R, p.capr, \
+                                                                    B.b, B.cnt2, e->d_ctr)
+    static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
+    switch (rv) {
+    case 1: DK_REPART_LAUNCH(512, 16, 4); break;
+    case 2: DK_REPART_LAUNCH(512, 8, 8); break;
+    case 3: DK_REPART_LAUNCH(256, 16, 4); break;
+    default: DK_REPART_LAUNCH(1024, 8, 8); break;
     }
+#undef DK_REPART_LAUNCH
+    DK_HIP(e, hipGetLastError());
+    stage_mark(e, "repart");
     return DK_OK;
 }
 
-// Returns DK_ERR_OVERFLOW (without touching e->err semantics beyond the message) when a bin
-// overflowed: the caller then runs the direct family on the whole batch, which is exact (OR is
-// idempotent, so records already inserted do no harm).
+inline dk_status sync_counters(dk_engine *e, const char *what)
+{
+    hipError_t h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    if (h != hipSuccess) return fail(e, DK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(h));
+    if (e->h_ctr->n_overflow)
+        return fail(e, DK_ERR_OVERFLOW, "bucket overflow (%llu records)", (unsigned long long)e->h_ctr->n_overflow);
+    return DK_OK;
+}
+
+// Returns DK_ERR_OVERFLOW when a piece overflowed: the caller then runs the direct family on the
+// whole batch, which is exact (OR is idempotent, so records already inserted do no harm).
 inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
 {
     BucketPlan p;
@@ -523,18 +672,14 @@ inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
     BucketBufs B;
     dk_status st = bucketed_partition(e, r, p, B);
     if (st == DK_OK) {
+        const PieceList pl{B.b, B.cnt2, p.R, p.capr};
         seg_insert_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-            s->d_words, B.b, B.cursor2, p.cap2, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
+            s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_insert launch failed: %s", hipGetErrorString(h));
         else stage_mark(e, "seg_insert");
     }
-    if (st == DK_OK) {
-        hipError_t h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
-        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
-        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "bucketed insert failed: %s", hipGetErrorString(h));
-        else if (e->h_ctr->n_overflow) st = fail(e, DK_ERR_OVERFLOW, "bucket overflow (%llu records)", (unsigned long long)e->h_ctr->n_overflow);
-    }
+    if (st == DK_OK) st = sync_counters(e, "bucketed insert");
     free_bufs(e, B);
     return st;
 }
@@ -545,25 +690,17 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
     if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs B;
     dk_status st = bucketed_partition(e, r, p, B);
-    auto sync_counters = [&]() -> dk_status {
-        hipError_t h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
-        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
-        if (h != hipSuccess) return fail(e, DK_ERR_HIP, "bucketed probe failed: %s", hipGetErrorString(h));
-        if (e->h_ctr->n_overflow) return fail(e, DK_ERR_OVERFLOW, "bucket overflow (%llu records)", (unsigned long long)e->h_ctr->n_overflow);
-        return DK_OK;
-    };
-    const uint64_t *list = B.b;
-    const uint32_t *list_cnt = B.cursor2;
+    PieceList list{B.b, B.cnt2, p.R, p.capr};
     if (st == DK_OK && s) {
+        const uint32_t miss_cap = p.R * p.capr;
         seg_probe_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-            s->d_words, B.b, B.cursor2, p.cap2, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, B.miss_cnt, e->d_ctr);
+            s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
         else stage_mark(e, "seg_probe");
-        list = B.a;
-        list_cnt = B.miss_cnt;
+        list = PieceList{B.a, B.miss_cnt, 1, miss_cap};
     }
-    if (st == DK_OK) st = sync_counters();
+    if (st == DK_OK) st = sync_counters(e, "bucketed probe");
     uint64_t n_absent = 0;
     if (st == DK_OK) {
         if (!s) {            // KmerCounter semantics: every valid k-mer is counted
@@ -578,12 +715,12 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
         if (st == DK_OK) st = pool_alloc(e, n_absent * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {
             seg_count_kernel<<<(unsigned)p.n_seg, CNT_THREADS, 0, e->stream>>>(
-                list, list_cnt, p.cap2, p.T, e->cfg.seed, e->cfg.min_count, n_absent, res->d_lo, res->d_cnt, e->d_ctr);
+                list, p.T, e->cfg.seed, e->cfg.min_count, n_absent, res->d_lo, res->d_cnt, e->d_ctr);
             hipError_t h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
             else stage_mark(e, "seg_count");
         }
-        if (st == DK_OK) st = sync_counters();
+        if (st == DK_OK) st = sync_counters(e, "bucketed count");
         if (st == DK_OK) res->n = e->h_ctr->n_emitted;
     }
     free_bufs(e, B);

@@ -36,6 +36,7 @@ struct Counters {               // device-side statistics of one operation
     unsigned long long n_emitted;
     unsigned long long n_overflow;  // bucketed: records diverted to the overflow list
     unsigned long long pad[2];
+    unsigned long long dbg[8];      // DK_STAMPS diagnostic builds only: per-phase cycle sums
 };
 
 // ---- ASCII -> packed stream ------------------------------------------------------------------
