@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "bucketed"])
     ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -116,11 +119,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    on_host = args.backend == "gloo"          # reductions of scalars go through host tensors under gloo
 
     if args.log2_bits == 0:
         args.log2_bits = 34 + max(0, (world - 1).bit_length())
@@ -150,10 +159,17 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        allreduce_bytes = or_allreduce_(filt, hip_or_fn(eng))
+        allreduce_bytes = or_allreduce_(filt, hip_or_fn(eng), stage_through_cpu=on_host)
         torch.cuda.synchronize()
         dist.barrier()
         allreduce_ms = (time.perf_counter() - t0) * 1e3
+    # every rank must now hold the same filter: compare bit counts across ranks
+    popc = kset.popcount()
+    filter_consistent = True
+    if world > 1:
+        pc = torch.tensor([popc, -popc], dtype=torch.int64, device="cpu" if on_host else dev)
+        dist.all_reduce(pc, op=dist.ReduceOp.MAX)
+        filter_consistent = bool(int(pc[0].item()) == -int(pc[1].item()))
 
     # ---- child membership pass: warmup + K timed steps -----------------------------------------
     child = dk.ReadBatch.synth(eng, gcfg, 2, first, args.reads)
@@ -181,10 +197,11 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        sdev = "cpu" if on_host else dev
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=sdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        ww = torch.tensor([stats["n_windows"]], dtype=torch.int64, device=dev)
+        ww = torch.tensor([stats["n_windows"]], dtype=torch.int64, device=sdev)
         dist.all_reduce(ww, op=dist.ReduceOp.SUM)
         windows_all = int(ww.item())
     else:
@@ -225,7 +242,8 @@ def main():
             "pass_stats": stats,
             "parent_build": {"insert_gkmers_s": insert_windows / (insert_ms * 1e-3) / 1e9 if insert_ms else None,
                              "insert_ms": insert_ms, "insert_stages_ms": insert_stages,
-                             "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes},
+                             "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes,
+                             "filter_bits_set": popc, "filter_identical_on_all_ranks": filter_consistent},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dk, eng, kset, gcfg, args, min(args.cpu_sample_reads, args.reads))

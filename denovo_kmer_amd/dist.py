@@ -32,10 +32,13 @@ def hip_or_fn(engine):
     return fn
 
 
-def or_allreduce_(filt, or_fn, group=None):
+def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
     """In-place bitwise-OR all-reduce of `filt` (1-D int64 tensor, one per rank, equal sizes).
 
     or_fn(dst, src, n_slices): dst |= OR of the n_slices contiguous slices in src.
+    stage_through_cpu: move the payload through host memory around each collective (for rehearsing
+    the GPU path over the gloo backend, which has no device all-to-all); the OR step still runs
+    wherever `filt` lives.
     Returns bytes sent per rank (for bandwidth reporting)."""
     world = dist.get_world_size(group)
     if world == 1:
@@ -44,11 +47,22 @@ def or_allreduce_(filt, or_fn, group=None):
     n = filt.numel()
     assert n % (2 * world) == 0, "filter words must split into 16-byte-aligned slices per rank"
     sl = n // world
-    recv = torch.empty_like(filt)
-    dist.all_to_all_single(recv, filt, group=group)          # recv[j*sl:(j+1)*sl] = rank j's slice `rank`
+    if stage_through_cpu:
+        send = filt.cpu()
+        recv_h = torch.empty_like(send)
+        dist.all_to_all_single(recv_h, send, group=group)
+        recv = recv_h.to(filt.device)
+    else:
+        recv = torch.empty_like(filt)
+        dist.all_to_all_single(recv, filt, group=group)      # recv[j*sl:(j+1)*sl] = rank j's slice `rank`
     reduced = recv[:sl]
     or_fn(reduced, recv[sl:], world - 1)
-    dist.all_gather_into_tensor(filt, reduced, group=group)
+    if stage_through_cpu:
+        out_h = torch.empty(n, dtype=filt.dtype)
+        dist.all_gather_into_tensor(out_h, reduced.cpu(), group=group)
+        filt.copy_(out_h)
+    else:
+        dist.all_gather_into_tensor(filt, reduced, group=group)
     return 2 * (world - 1) * sl * filt.element_size()
 
 

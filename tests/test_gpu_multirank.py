@@ -1,0 +1,78 @@
+"""Multi-rank GPU path rehearsed on ONE GPU: two processes (gloo rendezvous, collectives staged
+through the host because gloo has no device all-to-all) each build a partial parent filter with the
+HIP kernels, OR-all-reduce it with the HIP slice-OR kernel, probe their child shard, and merge the
+counts.  The result must equal the oracle on the whole input.  On an 8-GPU node the same code runs
+with backend nccl (RCCL) and no host staging -- that run belongs to the driver."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import denovo_kmer_amd as dk
+    from denovo_kmer_amd.dist import hip_or_fn, merge_counts, or_allreduce_, shard_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        gcfg = dk.synth_config(genome_len=100_000)
+        eng = dk.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=nh, seed=seed, device_id=0, mode=mode,
+                        rank=rank, world_size=world)
+        filt = torch.zeros((1 << log2_bits) // 64, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        ks = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
+        lo, hi = shard_range(n_reads, rank, world)
+        for s in (0, 1):
+            ks.insert_reads(dk.ReadBatch.synth(eng, gcfg, s, lo, hi - lo))
+        or_allreduce_(filt, hip_or_fn(eng), stage_through_cpu=True)
+        res = dk.KmerCounter(eng).child_only(dk.ReadBatch.synth(eng, gcfg, 2, lo, hi - lo), ks)
+        khi, klo, kcnt = res.to_host()
+        mhi, mlo, mcnt = merge_counts(khi, klo, kcnt, min_count=1)
+        q.put((rank, filt.cpu().numpy().view(np.uint64).copy(), mhi, mlo, mcnt))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["direct", "bucketed"])
+def test_two_ranks_one_gpu_match_whole_input_oracle(mode):
+    n_reads, k, log2_bits, nh, seed, world = 6000, 31, 24, 4, 31337, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_reads, k, log2_bits, nh, seed, mode, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ocfg = orc.synth_cfg(genome_len=100_000)
+    f = orc.new_filter(log2_bits)
+    for smp in (0, 1):
+        seq, off = orc.synth_reads(ocfg, smp, 0, n_reads)
+        orc.bloom_insert(f, log2_bits, nh, seed, k, True, seq, off)
+    cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+    km, cn, _ = orc.bloom_probe(f, log2_bits, nh, seed, k, True, cseq, coff)
+    for rank, filt, mhi, mlo, mcnt in outs:
+        assert np.array_equal(filt, f)
+        assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcnt, cn)
