@@ -40,19 +40,18 @@ constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
 constexpr int MAX_R = 4;                               // level-2 producer groups per coarse bin
 
-// Buckets are built from PRIVATE pieces, so the partition needs no global atomics at all:
+// Level-1 buckets are built from PRIVATE pieces, so the scan needs no global atomics at all:
 //   level 1: workgroup w of scan_part owns piece (bin b, w) = a[(b*G + w) * capw ...]
-//   level 2: workgroup (b, r) of repart reads the pieces (b, w) of its share of the producers and
-//            owns piece (segment s, r) = b[(s*R + r) * capr ...]
-// Running cursors live in LDS for the life of the workgroup; piece sizes are stored once at the end.
+//   level 2: one repart workgroup per tile of a level-1 piece appends to the per-segment regions
+//            b[s * cap2 ...] through global cursors (shared, hot write frontiers; see repart_kernel)
+// Level-1 cursors live in LDS for the life of the workgroup; piece sizes are stored once at the end.
 struct BucketPlan {
     int T;                 // log2(number of segments)
     int b1, b2;            // hash bits consumed at level 1 / level 2 (b1 + b2 = T, b2 >= 1)
     uint32_t p1, p2;       // bins at each level
     uint64_t n_seg;
     uint32_t G;            // scan_part workgroups = level-1 pieces per bin
-    uint32_t R;            // level-2 pieces per segment
-    uint32_t capw, capr;   // records per level-1 piece / level-2 piece
+    uint32_t capw, cap2;   // records per level-1 piece / per segment
     uint64_t n_max;        // upper bound on records of the batch
     int tile;              // positions per scan_part tile
 };
@@ -277,71 +276,85 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
 }
 
-// ---- level 2: workgroup (r = blockIdx.x, b = blockIdx.y) re-splits its share of the level-1 pieces
-// of coarse bin b by the next b2 hash bits into its own piece r of each of the bin's segments -------
+// ---- level 2: one workgroup per tile of a level-1 piece; records go to per-SEGMENT regions through
+// global cursors.  Shared write frontiers keep the DRAM pages and L2 lines being written few and
+// hot (every resident workgroup appends to the same 2^b2 segments of one coarse bin at a time),
+// which measured faster than private level-2 pieces; the cursor atomics are issued before the
+// scatter phase and only waited for after it, so their latency is covered.
 template <int THREADS, int PER_THREAD, int MIN_WAVES>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
-              int b1, int b2, uint32_t R, uint32_t capr, uint64_t *__restrict__ out,
-              uint32_t *__restrict__ cnt2, Counters *ctr)
+              uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, uint64_t *__restrict__ out,
+              uint32_t *__restrict__ cursor2, Counters *ctr)
 {
-    __shared__ SplitLds<THREADS, PER_THREAD> L;
     constexpr int TILE = THREADS * PER_THREAD;
+    __shared__ SplitLds<THREADS, PER_THREAD> L;
     const int tid = (int)threadIdx.x;
-    const uint32_t b = blockIdx.y, r = blockIdx.x;
+    const uint32_t b = blockIdx.y;
+    const uint32_t w = blockIdx.x / tiles_per_piece, t0 = (blockIdx.x % tiles_per_piece) * TILE;
+    const uint64_t piece = (uint64_t)b * G + w;
+    uint32_t n = cnt1[piece];
+    if (n > capw) n = capw;
+    if (t0 >= n) return;
     const int nbins = 1 << b2;
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
-    multisplit_init(L, nbins);
-    Stamps st;
-    const uint32_t per = (G + R - 1) / R;
-    const uint32_t w_lo = r * per, w_hi = (w_lo + per < G) ? w_lo + per : G;
-    uint32_t n_records = 0, n_overflow = 0;
-    const uint32_t *pcnt = cnt1 + (uint64_t)b * G;
-    const uint64_t *pin = in + (uint64_t)b * G * capw;
-    auto piece_size = [&](uint32_t w) -> uint32_t { const uint32_t c = pcnt[w]; return c < capw ? c : capw; };
-    auto load_tile = [&](uint32_t w, uint32_t t0, uint32_t n, uint64_t (&h)[PER_THREAD]) {
-        const uint64_t *src = pin + (uint64_t)w * capw;
+    for (int i = tid; i < MAX_BINS; i += THREADS) L.cnt[i] = 0;
+    const uint64_t *src = in + piece * capw;
+    uint64_t hs[PER_THREAD];
 #pragma unroll
-        for (int j = 0; j < PER_THREAD; j++) {
-            const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
-            h[j] = i < n ? src[i] : 0;
-        }
-    };
-    // walk the (piece, tile) sequence with the next tile's records already in flight
-    uint32_t w = w_lo, t0 = 0, n = 0;
-    while (w < w_hi && (n = piece_size(w)) == 0) w++;
-    uint64_t hs[PER_THREAD], nx[PER_THREAD];
-    if (w < w_hi) load_tile(w, 0, n, hs);
-#pragma unroll 1
-    while (w < w_hi) {
-        uint32_t nw = w, nt0 = t0 + TILE, nn = n;
-        if (nt0 >= nn) {
-            nt0 = 0;
-            nw++;
-            while (nw < w_hi && (nn = piece_size(nw)) == 0) nw++;
-        }
-        if (nw < w_hi) load_tile(nw, nt0, nn, nx);
-        uint32_t valid = 0;
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; j++) {
-            const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
-            if (i < n) {
-                valid |= 1u << j;
-                atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
-            }
-        }
-        lds_barrier();                                   // A
-        multisplit_flush(L, hs, valid, nbins, bin_of, (uint64_t)b << b2, (uint64_t)R * capr, (uint64_t)r * capr,
-                         capr, out, n_records, n_overflow, st);
-#pragma unroll
-        for (int j = 0; j < PER_THREAD; j++) hs[j] = nx[j];
-        w = nw;
-        t0 = nt0;
-        n = nn;
+    for (int j = 0; j < PER_THREAD; j++) {
+        const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+        hs[j] = i < n ? src[i] : 0;
     }
-    st.flush(ctr, 4);
-    multisplit_finish(L, nbins, (uint64_t)b << b2, R, r, capr, cnt2);
+    __syncthreads();
+    uint32_t valid = 0;
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; j++) {
+        const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+        if (i < n) {
+            valid |= 1u << j;
+            atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+        }
+    }
+    lds_barrier();                                       // A
+    // scan (lane = bin) and reserve the segment ranges; the atomics' results are used after the scatter
+    uint32_t *cursor = cursor2 + ((uint64_t)b << b2);
+    const int wv = tid >> 6, lane = tid & 63;
+    uint32_t g = 0, ex = 0;
+    if (wv * 64 < nbins) {
+        const uint32_t c = tid < nbins ? L.cnt[tid] : 0;
+        uint32_t below = 0;
+#pragma unroll
+        for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
+            const uint32_t x = L.cnt[64 * v + lane];
+            below += v < wv ? x : 0u;
+        }
+        below = wave_total(below);
+        ex = below + wave_incl_scan(c) - c;
+        if (tid < nbins) {
+            L.off[tid] = ex;
+            if (c) g = atomicAdd(&cursor[tid], c);
+            if (tid == nbins - 1) L.total = ex + c;
+        }
+    }
+    lds_barrier();                                       // B
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; j++)
+        if ((valid >> j) & 1u) L.stage[atomicAdd(&L.off[bin_of(hs[j])], 1u)] = hs[j];
+    if (tid < nbins) L.delta[tid] = g - ex;
+    lds_barrier();                                       // C
+    const uint32_t total = L.total;
+    const uint64_t seg0 = (uint64_t)b << b2;
+    uint32_t n_overflow = 0;
+#pragma unroll 4
+    for (uint32_t i = tid; i < total; i += THREADS) {
+        const uint64_t h = L.stage[i];
+        const uint32_t bin = bin_of(h);
+        const uint32_t idx = i + L.delta[bin];
+        if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = h;
+        else n_overflow++;
+    }
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
 }
@@ -569,17 +582,15 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
     const uint64_t n_tiles = (r->n_bases + p->tile - 1) / p->tile;
     if (n_tiles > 0xFFFFFFFFULL) return false;
     p->G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), (uint64_t)e->n_cu * blocks_per_cu);
-    static const uint32_t r_env = [] { const char *v = getenv("DK_R"); return v ? (uint32_t)atoi(v) : 4u; }();
-    p->R = std::min<uint32_t>(std::min<uint32_t>(MAX_R, std::max<uint32_t>(r_env, 1)), p->G);
-    // expected piece sizes, from the largest share a producer can get (tiles and producer groups
-    // are dealt round-robin, so shares differ by at most one tile / one producer)
+    // expected piece size from the largest share a producer can get (tiles are dealt round-robin,
+    // so shares differ by at most one tile)
     const uint64_t tiles_per_wg = (n_tiles + p->G - 1) / p->G;
     const double share1 = (double)std::min<uint64_t>(p->n_max, tiles_per_wg * (uint64_t)p->tile);
     const double m1 = share1 / (double)p->p1;
-    const double m2 = share1 * (double)((p->G + p->R - 1) / p->R) / (double)p->n_seg;
-    if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 piece cursors
+    const double m2 = (double)p->n_max / (double)p->n_seg;
+    if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 cursors
     p->capw = piece_capacity(m1, 4.0);
-    p->capr = piece_capacity(m2, std::max(4.0, 64.0 / p->R));    // copies of one k-mer spread over the R producer groups
+    p->cap2 = piece_capacity(m2, 64.0);
     return true;
 }
 
@@ -593,9 +604,9 @@ inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases)
 }
 
 struct BucketBufs {
-    uint64_t *a = nullptr, *b = nullptr;      // level-1 pieces (later: absent lists) / segment pieces
-    uint32_t *cnt = nullptr;                  // cnt1 [p1 * G] | cnt2 [n_seg * R] | miss_cnt [n_seg]
-    uint32_t *cnt1 = nullptr, *cnt2 = nullptr, *miss_cnt = nullptr;
+    uint64_t *a = nullptr, *b = nullptr;      // level-1 pieces (later: absent lists) / segment regions
+    uint32_t *cnt = nullptr;                  // cnt1 [p1 * G] | cursor2 [n_seg] | miss_cnt [n_seg]
+    uint32_t *cnt1 = nullptr, *cursor2 = nullptr, *miss_cnt = nullptr;
 };
 
 inline void free_bufs(dk_engine *e, BucketBufs &B)
@@ -605,18 +616,19 @@ inline void free_bufs(dk_engine *e, BucketBufs &B)
     pool_free(e, B.cnt);
 }
 
-// scan_part + repart: afterwards B.b / B.cnt2 hold every record of the batch grouped by segment
+// scan_part + repart: afterwards B.b / B.cursor2 hold every record of the batch grouped by segment
 inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p, BucketBufs &B)
 {
-    const uint64_t seg_recs = p.n_seg * (uint64_t)p.R * p.capr;
+    const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
     const uint64_t lvl1_recs = (uint64_t)p.p1 * p.G * p.capw;
     DK_TRY(pool_alloc(e, std::max(seg_recs, lvl1_recs) * 8, (void **)&B.a));
     DK_TRY(pool_alloc(e, seg_recs * 8, (void **)&B.b));
-    const uint64_t n1 = (uint64_t)p.p1 * p.G, n2 = p.n_seg * p.R;
-    DK_TRY(pool_alloc(e, (n1 + n2 + p.n_seg) * 4, (void **)&B.cnt));
+    const uint64_t n1 = (uint64_t)p.p1 * p.G;
+    DK_TRY(pool_alloc(e, (n1 + 2 * p.n_seg) * 4, (void **)&B.cnt));
     B.cnt1 = B.cnt;
-    B.cnt2 = B.cnt + n1;
-    B.miss_cnt = B.cnt2 + n2;
+    B.cursor2 = B.cnt + n1;
+    B.miss_cnt = B.cursor2 + p.n_seg;
+    DK_HIP(e, hipMemsetAsync(B.cursor2, 0, p.n_seg * 4, e->stream));
 
     StreamView sv;
     sv.bases = r->d_bases;
@@ -637,17 +649,9 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #undef DK_SCAN_LAUNCH
     DK_HIP(e, hipGetLastError());
     stage_mark(e, "scan_part");
-#define DK_REPART_LAUNCH(TH, PT, W)                                                                              \
-    repart_kernel<TH, PT, W><<<dim3(p.R, p.p1), TH, 0, e->stream>>>(B.a, B.cnt1, p.G, p.capw, p.b1, p.b2, p.R, p.capr, \
-                                                                    B.b, B.cnt2, e->d_ctr)
-    static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
-    switch (rv) {
-    case 1: DK_REPART_LAUNCH(512, 16, 4); break;
-    case 2: DK_REPART_LAUNCH(512, 8, 8); break;
-    case 3: DK_REPART_LAUNCH(256, 16, 4); break;
-    default: DK_REPART_LAUNCH(1024, 8, 8); break;
-    }
-#undef DK_REPART_LAUNCH
+    const uint32_t tpp = (p.capw + PART_TILE - 1) / PART_TILE;
+    repart_kernel<PART_THREADS, PART_PER_THREAD, 8><<<dim3(p.G * tpp, p.p1), PART_THREADS, 0, e->stream>>>(
+        B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, e->d_ctr);
     DK_HIP(e, hipGetLastError());
     stage_mark(e, "repart");
     return DK_OK;
@@ -672,7 +676,7 @@ inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
     BucketBufs B;
     dk_status st = bucketed_partition(e, r, p, B);
     if (st == DK_OK) {
-        const PieceList pl{B.b, B.cnt2, p.R, p.capr};
+        const PieceList pl{B.b, B.cursor2, 1, p.cap2};
         seg_insert_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
             s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
         hipError_t h = hipGetLastError();
@@ -690,9 +694,9 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
     if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs B;
     dk_status st = bucketed_partition(e, r, p, B);
-    PieceList list{B.b, B.cnt2, p.R, p.capr};
+    PieceList list{B.b, B.cursor2, 1, p.cap2};
     if (st == DK_OK && s) {
-        const uint32_t miss_cap = p.R * p.capr;
+        const uint32_t miss_cap = p.cap2;
         seg_probe_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
             s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         hipError_t h = hipGetLastError();
