@@ -133,7 +133,7 @@ __device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD> &L
 // `valid` has bit j set when hs[j] holds a record (already counted into L.cnt by the caller).
 template <int THREADS, int PER_THREAD, class BinOf>
 __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &L, const uint64_t (&hs)[PER_THREAD],
-                                                 uint32_t valid, int nbins, BinOf bin_of,
+                                                 const uint32_t (&rk)[PER_THREAD], uint32_t valid, int nbins, BinOf bin_of,
                                                  uint64_t bin_base, uint64_t bin_stride, uint64_t piece_off,
                                                  uint32_t cap, uint64_t *__restrict__ out,
                                                  uint32_t &n_records, uint32_t &n_overflow, Stamps &st)
@@ -166,10 +166,10 @@ __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &
     lds_barrier();                                       // B
     st.mark(1);
     if (tid < nbins) L.cnt[tid] = 0;                     // every scanning wave has read it
-    // off[bin] now serves as the running slot counter of the bin inside the stage
+    // rk[j] = rank of the record inside its bin for this tile (from the counting atomic)
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++)
-        if ((valid >> j) & 1u) L.stage[atomicAdd(&L.off[bin_of(hs[j])], 1u)] = hs[j];
+        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j])] + rk[j]] = hs[j];
     lds_barrier();                                       // C
     st.mark(2);
     const uint32_t total = L.total;
@@ -246,6 +246,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         const uint64_t mv = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
 
         uint64_t hs[PER_THREAD];
+        uint32_t rk[PER_THREAD];
         uint32_t valid = 0;
         uint64_t rc = 0;
 #pragma unroll
@@ -258,16 +259,17 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             uint64_t km = fwd;
             if (canonical && rc < fwd) km = rc;
             hs[j] = fmix64(km ^ seed);
+            rk[j] = 0;
             if (!bad && p0 + j < s.n_bases) {
                 valid |= 1u << j;
-                atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+                rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
             }
             // keep the windows sequential: interleaving the eight hash chains costs ~40 VGPRs and
             // with them half the resident waves, which hide latency better than in-wave ILP does
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();                                   // A
-        multisplit_flush(L, hs, valid, nbins, bin_of, 0, G * capw, w * capw, capw, out, n_records, n_overflow, st);
+        multisplit_flush(L, hs, rk, valid, nbins, bin_of, 0, G * capw, w * capw, capw, out, n_records, n_overflow, st);
     }
     st.flush(ctr, 0);
     multisplit_finish(L, nbins, 0, (uint32_t)G, (uint32_t)w, capw, cnt1);
@@ -309,12 +311,14 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
     }
     __syncthreads();
     uint32_t valid = 0;
+    uint32_t rk[PER_THREAD];
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++) {
         const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+        rk[j] = 0;
         if (i < n) {
             valid |= 1u << j;
-            atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+            rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
         }
     }
     lds_barrier();                                       // A
@@ -341,7 +345,7 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
     lds_barrier();                                       // B
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++)
-        if ((valid >> j) & 1u) L.stage[atomicAdd(&L.off[bin_of(hs[j])], 1u)] = hs[j];
+        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j])] + rk[j]] = hs[j];
     if (tid < nbins) L.delta[tid] = g - ex;
     lds_barrier();                                       // C
     const uint32_t total = L.total;
@@ -419,13 +423,25 @@ seg_insert_kernel(unsigned long long *filter, PieceList pl, int n_hashes, int bl
     if (n == 0) return;                       // nothing to add: leave the segment untouched
     load_segment(seg, filter, seg_id);
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += SEG_THREADS) {
-        const uint64_t h = sp.at(i);
-        const uint32_t blk = (uint32_t)(h >> blk_shift) & (SEG_BLOCKS - 1);
-        const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
-        for (int j = 0; j < n_hashes; j++) {
-            const uint32_t bit = (a + (uint32_t)j * d) & 511;
-            atomicOr(&seg[blk * 16 + (bit >> 5)], 1u << (bit & 31));
+    constexpr int UNROLL = 4;
+    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
+        uint64_t h[UNROLL];
+        bool have[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
+            have[u] = i < n;
+            h[u] = have[u] ? sp.at(i) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            if (!have[u]) continue;
+            const uint32_t blk = (uint32_t)(h[u] >> blk_shift) & (SEG_BLOCKS - 1);
+            const uint32_t a = (uint32_t)(h[u] & 511), d = (uint32_t)((h[u] >> 9) & 511) | 1u;
+            for (int j = 0; j < n_hashes; j++) {
+                const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                atomicOr(&seg[blk * 16 + (bit >> 5)], 1u << (bit & 31));
+            }
         }
     }
     __syncthreads();
@@ -452,25 +468,34 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, in
     load_segment(seg, filter, seg_id);
     __syncthreads();
     uint64_t *dst = miss + seg_id * miss_cap;
-    const uint32_t n_round = (n + 63) & ~63u;
-    for (uint32_t i = threadIdx.x; i < n_round; i += SEG_THREADS) {
-        const bool have = i < n;
-        const uint64_t h = have ? sp.at(i) : 0;
-        const uint32_t blk = (uint32_t)(h >> blk_shift) & (SEG_BLOCKS - 1);
-        const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
-        bool all = true;
-        for (int j = 0; j < n_hashes; j++) {
-            const uint32_t bit = (a + (uint32_t)j * d) & 511;
-            all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
+    constexpr int UNROLL = 4;                 // records in flight per thread: loads first, then the LDS tests
+    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
+        uint64_t h[UNROLL];
+        bool have[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
+            have[u] = i < n;
+            h[u] = have[u] ? sp.at(i) : 0;
         }
-        const bool absent = have && !all;
-        const uint64_t b = __ballot(absent);
-        if (b) {
-            const int leader = __ffsll((long long)b) - 1;
-            uint32_t wbase = 0;
-            if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
-            wbase = __shfl(wbase, leader);
-            if (absent) dst[wbase + popc_below(b)] = h;
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t blk = (uint32_t)(h[u] >> blk_shift) & (SEG_BLOCKS - 1);
+            const uint32_t a = (uint32_t)(h[u] & 511), d = (uint32_t)((h[u] >> 9) & 511) | 1u;
+            bool all = true;
+            for (int j = 0; j < n_hashes; j++) {
+                const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
+            }
+            const bool absent = have[u] && !all;
+            const uint64_t b = __ballot(absent);
+            if (b) {
+                const int leader = __ffsll((long long)b) - 1;
+                uint32_t wbase = 0;
+                if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
+                wbase = __shfl(wbase, leader);
+                if (absent) dst[wbase + popc_below(b)] = h[u];
+            }
         }
     }
     __syncthreads();
@@ -501,18 +526,30 @@ seg_count_kernel(PieceList pl, int T, uint64_t seed, uint32_t min_count, uint64_
     for (uint32_t r = 0; r < rounds; r++) {
         for (int i = (int)threadIdx.x; i < CNT_SLOTS; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += CNT_THREADS) {
-            const uint64_t h = sp.at(i);
-            const uint32_t rr = (uint32_t)((((h >> 33) & 0x1FFF) * rounds) >> 13);
-            if (rr != r) continue;
-            uint32_t slot = (uint32_t)(h >> 20) & (CNT_SLOTS - 1);
-            int tries = 0;
-            for (; tries < CNT_SLOTS; tries++) {
-                const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
-                if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
-                slot = (slot + 1) & (CNT_SLOTS - 1);
+        constexpr int UNROLL = 8;             // records in flight per thread (loads first, then the LDS inserts)
+        for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * CNT_THREADS) {
+            uint64_t hv[UNROLL];
+            bool mine_r[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + (uint32_t)u * CNT_THREADS + threadIdx.x;
+                hv[u] = i < n ? sp.at(i) : 0;
+                mine_r[u] = i < n;
             }
-            if (tries == CNT_SLOTS) n_fail++;       // table full: host falls back to the direct family
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint64_t h = hv[u];
+                const uint32_t rr = (uint32_t)((((h >> 33) & 0x1FFF) * rounds) >> 13);
+                if (!mine_r[u] || rr != r) continue;
+                uint32_t slot = (uint32_t)(h >> 20) & (CNT_SLOTS - 1);
+                int tries = 0;
+                for (; tries < CNT_SLOTS; tries++) {
+                    const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
+                    if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
+                    slot = (slot + 1) & (CNT_SLOTS - 1);
+                }
+                if (tries == CNT_SLOTS) n_fail++;       // table full: host falls back to the direct family
+            }
         }
         __syncthreads();
         // emit: count, scan, reserve, write
@@ -649,9 +686,21 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #undef DK_SCAN_LAUNCH
     DK_HIP(e, hipGetLastError());
     stage_mark(e, "scan_part");
-    const uint32_t tpp = (p.capw + PART_TILE - 1) / PART_TILE;
-    repart_kernel<PART_THREADS, PART_PER_THREAD, 8><<<dim3(p.G * tpp, p.p1), PART_THREADS, 0, e->stream>>>(
-        B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, e->d_ctr);
+#define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
+    do {                                                                                                  \
+        const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
+        repart_kernel<TH, PT, W><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                             \
+            B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, e->d_ctr);                  \
+    } while (0)
+    static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
+    switch (rv) {
+    case 1: DK_REPART_LAUNCH(512, 8, 8); break;
+    case 2: DK_REPART_LAUNCH(512, 16, 4); break;
+    case 3: DK_REPART_LAUNCH(256, 16, 4); break;
+    case 4: DK_REPART_LAUNCH(256, 8, 8); break;
+    default: DK_REPART_LAUNCH(1024, 8, 8); break;
+    }
+#undef DK_REPART_LAUNCH
     DK_HIP(e, hipGetLastError());
     stage_mark(e, "repart");
     return DK_OK;
