@@ -328,6 +328,32 @@ def test_synthetic_trio_parity_config0_scale(mode, k, log2_bits):
         assert eng.timings()["total_ms"] > 0
 
 
+@pytest.mark.parametrize("mode,k", [("direct", 51), ("direct", 31), ("bucketed", 31), ("direct", 64)])
+def test_long_reads_config4_shape(mode, k):
+    # BASELINE.json configs[4] shape: ONT-style 10 kb reads with 5 % errors (k=51 runs on the direct
+    # family; the bucketed family covers k <= 32)
+    d = dk()
+    n_reads, L, log2_bits = 300, 10_000, 26
+    ocfg = orc.synth_cfg(genome_len=400_000, read_len=L, err_rate=0.05)
+    gcfg = d.synth_config(genome_len=400_000, read_len=L, err_rate=0.05)
+    with make_engine(mode, k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=51) as eng:
+        ks = d.KmerSet(eng)
+        f = orc.new_filter(log2_bits)
+        for s in (0, 1):
+            ist = ks.insert_reads(d.ReadBatch.synth(eng, gcfg, s, 0, n_reads))
+            assert_family_ran(eng)
+            seq, off = orc.synth_reads(ocfg, s, 0, n_reads)
+            oist = orc.bloom_insert(f, log2_bits, 4, 51, k, True, seq, off)
+            assert ist["n_valid"] == oist["n_valid"] and ist["n_windows"] == n_reads * (L - k + 1)
+        assert np.array_equal(ks.to_host(), f)
+        res = d.KmerCounter(eng).child_only(d.ReadBatch.synth(eng, gcfg, 2, 0, n_reads), ks)
+        assert_family_ran(eng)
+        cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+        km, cn, pst = orc.bloom_probe(f, log2_bits, 4, 51, k, True, cseq, coff)
+        assert_result_equals(res, km, cn)
+        assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
+
+
 @pytest.mark.parametrize("log2_bits", [29, 31])
 def test_two_level_partition_large_filter(log2_bits):
     # filters above 2^9 segments take the two-level multisplit (scan_part + repart)
