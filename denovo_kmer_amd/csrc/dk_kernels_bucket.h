@@ -507,7 +507,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, in
 
 // exact counting of one segment's absent records in an LDS hash table, `rounds` sub-ranges at a time
 __global__ void __launch_bounds__(CNT_THREADS)
-seg_count_kernel(PieceList pl, int T, uint64_t seed, uint32_t min_count, uint64_t out_cap,
+seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count, uint64_t out_cap,
                  uint64_t *__restrict__ out_kmer, uint32_t *__restrict__ out_cnt, Counters *ctr)
 {
     __shared__ unsigned long long keys[CNT_SLOTS];
@@ -515,16 +515,23 @@ seg_count_kernel(PieceList pl, int T, uint64_t seed, uint32_t min_count, uint64_
     __shared__ uint32_t wave_sums[CNT_THREADS / 64];
     __shared__ uint32_t total;
     __shared__ unsigned long long gbase;
-    const uint64_t seg_id = blockIdx.x;
+    uint32_t n_distinct = 0, n_fail = 0;
+    // persistent: a workgroup walks segments blockIdx.x, +gridDim.x, ... (launching one tiny
+    // workgroup per segment cost ~50 ns of wall time each at 2^18 segments)
+    for (uint64_t seg_id = blockIdx.x; seg_id < n_seg; seg_id += gridDim.x) {
     const SegPieces sp = seg_pieces(pl, seg_id);
     const uint32_t n = sp.total();
-    if (n == 0) return;
+    if (n == 0) continue;
     // a value no record of this segment can take: its top T bits differ from the segment id
     const unsigned long long EMPTY = (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
     const uint32_t rounds = (n + CNT_SLOTS / 2 - 1) / (CNT_SLOTS / 2);
-    uint32_t n_distinct = 0, n_fail = 0;
+    // small segments use a smaller power-of-two part of the table (load <= 1/2): clearing and
+    // scanning 4096 slots for a few hundred records dominated at large filters
+    uint32_t slots = 256;
+    while (slots < 2 * n && slots < (uint32_t)CNT_SLOTS) slots <<= 1;
+    const uint32_t slot_mask = slots - 1;
     for (uint32_t r = 0; r < rounds; r++) {
-        for (int i = (int)threadIdx.x; i < CNT_SLOTS; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
+        for (uint32_t i = threadIdx.x; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
         __syncthreads();
         constexpr int UNROLL = 8;             // records in flight per thread (loads first, then the LDS inserts)
         for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * CNT_THREADS) {
@@ -541,27 +548,27 @@ seg_count_kernel(PieceList pl, int T, uint64_t seed, uint32_t min_count, uint64_
                 const uint64_t h = hv[u];
                 const uint32_t rr = (uint32_t)((((h >> 33) & 0x1FFF) * rounds) >> 13);
                 if (!mine_r[u] || rr != r) continue;
-                uint32_t slot = (uint32_t)(h >> 20) & (CNT_SLOTS - 1);
-                int tries = 0;
-                for (; tries < CNT_SLOTS; tries++) {
+                uint32_t slot = (uint32_t)(h >> 20) & slot_mask;
+                uint32_t tries = 0;
+                for (; tries < slots; tries++) {
                     const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
                     if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
-                    slot = (slot + 1) & (CNT_SLOTS - 1);
+                    slot = (slot + 1) & slot_mask;
                 }
-                if (tries == CNT_SLOTS) n_fail++;       // table full: host falls back to the direct family
+                if (tries == slots) n_fail++;           // table full: host falls back to the direct family
             }
         }
         __syncthreads();
         // emit: count, scan, reserve, write
         uint32_t mine = 0;
-        for (int s = (int)threadIdx.x; s < CNT_SLOTS; s += CNT_THREADS) {
+        for (uint32_t s = threadIdx.x; s < slots; s += CNT_THREADS) {
             if (keys[s] != EMPTY) { n_distinct++; if (cnts[s] >= min_count) mine++; }
         }
         const uint32_t ex = block_excl_scan(mine, wave_sums, &total);
         if (threadIdx.x == 0) gbase = total ? atomicAdd(&ctr->n_emitted, (unsigned long long)total) : 0ULL;
         __syncthreads();
         uint64_t o = gbase + ex;
-        for (int s = (int)threadIdx.x; s < CNT_SLOTS; s += CNT_THREADS) {
+        for (uint32_t s = threadIdx.x; s < slots; s += CNT_THREADS) {
             if (keys[s] != EMPTY && cnts[s] >= min_count) {
                 if (o < out_cap) {
                     out_kmer[o] = unfmix64(keys[s]) ^ seed;
@@ -571,6 +578,7 @@ seg_count_kernel(PieceList pl, int T, uint64_t seed, uint32_t min_count, uint64_
             }
         }
         __syncthreads();
+    }
     }
     n_distinct = (uint32_t)wave_sum(n_distinct);
     n_fail = (uint32_t)wave_sum(n_fail);
@@ -767,8 +775,9 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
         st = pool_alloc(e, n_absent * 8, (void **)&res->d_lo);
         if (st == DK_OK) st = pool_alloc(e, n_absent * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {
-            seg_count_kernel<<<(unsigned)p.n_seg, CNT_THREADS, 0, e->stream>>>(
-                list, p.T, e->cfg.seed, e->cfg.min_count, n_absent, res->d_lo, res->d_cnt, e->d_ctr);
+            const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 12);
+            seg_count_kernel<<<cgrid, CNT_THREADS, 0, e->stream>>>(
+                list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, n_absent, res->d_lo, res->d_cnt, e->d_ctr);
             hipError_t h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
             else stage_mark(e, "seg_count");
