@@ -213,13 +213,15 @@ def main():
         dom = max(stages, key=stages.get)
         dom_bytes = stage_algorithmic_bytes(dom, stats, filter_bytes, args.read_len, args.k)
         achieved = dom_bytes / (stages[dom] * 1e-3) / 1e9 if dom_bytes else None
+        # HBM bytes of the dominant kernel from the committed PMC passes (profiles/traffic.json:
+        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs), same configuration only
         traffic = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
                 tj = json.load(open(prof))
-                if tj.get("kernel_stage") == dom and tj.get("reads") == args.reads and tj.get("log2_bits") == args.log2_bits:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("reads") == args.reads and tj.get("log2_bits") == args.log2_bits and world == 1:
+                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
