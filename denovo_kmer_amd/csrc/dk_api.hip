@@ -209,6 +209,9 @@ static dk_status probe_direct(dk_engine *e, dk_set *s, const dk_reads *r, dk_res
     cleanup();
     if (st != DK_OK) return st;
     res->n = e->h_ctr->n_emitted;
+    res->n_regions = 1;
+    res->region_cap = n_cand;
+    res->region_n[0] = res->n;
     return DK_OK;
 }
 
@@ -766,6 +769,9 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
     res->d_lo = res->d_hi = nullptr;
     res->d_cnt = nullptr;
     res->n = 0;
+    res->n_regions = 1;
+    res->region_cap = 0;
+    memset(res->region_n, 0, sizeof res->region_n);
     res->wide = e->cfg.k > 32;
     hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
     if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
@@ -783,6 +789,8 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
                 res->d_lo = nullptr;
                 res->d_cnt = nullptr;
                 res->n = 0;
+                res->n_regions = 1;
+                res->region_cap = 0;
                 h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
                 st = h == hipSuccess ? DK_OK : fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h));
                 stage_mark(e, "overflow_redo");
@@ -820,23 +828,60 @@ dk_status dk_result_copy(const dk_result *res, uint64_t *kmers_lo, uint64_t *kme
     dk_engine *e = res->e;
     if (res->n == 0) return DK_OK;
     CHECK_ARG(e, kmers_lo != nullptr && counts != nullptr);
+    CHECK_ARG(e, kmers_hi != nullptr || !res->wide);
     DK_HIP(e, hipSetDevice(e->device));
-    DK_HIP(e, hipMemcpyAsync(kmers_lo, res->d_lo, res->n * 8, hipMemcpyDeviceToHost, e->stream));
-    if (kmers_hi) {
-        if (res->wide) DK_HIP(e, hipMemcpyAsync(kmers_hi, res->d_hi, res->n * 8, hipMemcpyDeviceToHost, e->stream));
-        else memset(kmers_hi, 0, res->n * 8);
-    } else {
-        CHECK_ARG(e, !res->wide);
+    uint64_t done = 0;
+    for (uint32_t r = 0; r < res->n_regions; r++) {          // stitch the regions into dense host arrays
+        const uint64_t cnt = res->region_n[r], src = (uint64_t)r * res->region_cap;
+        if (!cnt) continue;
+        DK_HIP(e, hipMemcpyAsync(kmers_lo + done, res->d_lo + src, cnt * 8, hipMemcpyDeviceToHost, e->stream));
+        if (kmers_hi && res->wide)
+            DK_HIP(e, hipMemcpyAsync(kmers_hi + done, res->d_hi + src, cnt * 8, hipMemcpyDeviceToHost, e->stream));
+        DK_HIP(e, hipMemcpyAsync(counts + done, res->d_cnt + src, cnt * 4, hipMemcpyDeviceToHost, e->stream));
+        done += cnt;
     }
-    DK_HIP(e, hipMemcpyAsync(counts, res->d_cnt, res->n * 4, hipMemcpyDeviceToHost, e->stream));
+    if (kmers_hi && !res->wide) memset(kmers_hi, 0, res->n * 8);
     DK_HIP(e, hipStreamSynchronize(e->stream));
     return DK_OK;
 }
 
-dk_status dk_result_device_view(const dk_result *res, const void **d_kmers_lo, const void **d_kmers_hi,
+dk_status dk_result_device_view(const dk_result *cres, const void **d_kmers_lo, const void **d_kmers_hi,
                                 const void **d_counts, uint64_t *n)
 {
-    if (!res) return DK_ERR_INVALID_ARG;
+    if (!cres) return DK_ERR_INVALID_ARG;
+    dk_result *res = const_cast<dk_result *>(cres);
+    dk_engine *e = res->e;
+    if (res->n_regions > 1 && res->n) {
+        // first device view of a regioned result: compact it into dense arrays (device-to-device)
+        DK_HIP(e, hipSetDevice(e->device));
+        uint64_t *lo = nullptr;
+        uint32_t *cnt = nullptr;
+        DK_TRY(pool_alloc(e, res->n * 8, (void **)&lo));
+        dk_status st = pool_alloc(e, res->n * 4, (void **)&cnt);
+        if (st != DK_OK) { pool_free(e, lo); return st; }
+        uint64_t done = 0;
+        hipError_t h = hipSuccess;
+        for (uint32_t r = 0; r < res->n_regions && h == hipSuccess; r++) {
+            const uint64_t c = res->region_n[r], src = (uint64_t)r * res->region_cap;
+            if (!c) continue;
+            h = hipMemcpyAsync(lo + done, res->d_lo + src, c * 8, hipMemcpyDeviceToDevice, e->stream);
+            if (h == hipSuccess) h = hipMemcpyAsync(cnt + done, res->d_cnt + src, c * 4, hipMemcpyDeviceToDevice, e->stream);
+            done += c;
+        }
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+        if (h != hipSuccess) {
+            pool_free(e, lo);
+            pool_free(e, cnt);
+            return fail(e, DK_ERR_HIP, "compacting result regions failed: %s", hipGetErrorString(h));
+        }
+        pool_free(e, res->d_lo);
+        pool_free(e, res->d_cnt);
+        res->d_lo = lo;
+        res->d_cnt = cnt;
+        res->n_regions = 1;
+        res->region_cap = res->n;
+        res->region_n[0] = res->n;
+    }
     if (d_kmers_lo) *d_kmers_lo = res->d_lo;
     if (d_kmers_hi) *d_kmers_hi = res->d_hi;
     if (d_counts) *d_counts = res->d_cnt;

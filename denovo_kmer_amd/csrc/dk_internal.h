@@ -52,6 +52,13 @@ struct dk_result {
     uint32_t *d_cnt;
     uint64_t n;
     bool wide;
+    // Region r of the arrays holds region_n[r] entries starting at r * region_cap.  The direct
+    // family writes one dense region; the bucketed count kernel appends through RESULT_REGIONS
+    // independent fill counters (one global counter saturates near 10^8 atomics/s) and the regions
+    // are stitched on copy-out, or compacted on the first dk_result_device_view.
+    uint32_t n_regions;
+    uint64_t region_cap;
+    uint64_t region_n[dk::RESULT_REGIONS];
 };
 
 namespace dk {

@@ -34,8 +34,6 @@ constexpr int MAX_BINS = 1 << MAX_BIN_BITS;
 constexpr int CURSOR_STRIDE = 32;                      // level-1 cursors on separate 128-B lines
 
 constexpr int SEG_THREADS = 1024;
-constexpr int CNT_THREADS = 256;
-constexpr int CNT_SLOTS = 4096;                        // LDS hash table of seg_count
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
 constexpr int MAX_R = 4;                               // level-2 producer groups per coarse bin
@@ -505,80 +503,188 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, in
     }
 }
 
-// exact counting of one segment's absent records in an LDS hash table, `rounds` sub-ranges at a time
+// Exact counting of one segment's absent records.
+// Most absent k-mers are singletons (sequencing errors), so a hash table for all of them is wasted
+// work.  Two 64-Kbit LDS bitmaps classify the records first: bit(h) set twice => the record MAY have
+// a twin (true duplicate or bitmap collision) and goes through a small LDS hash table; every other
+// record is provably unique and is emitted with count 1 straight from registers.  Exact for any
+// input: all copies of a k-mer share a bit, so all of them are flagged.
+// Two geometries: <512 threads, 2048 slots, 64-Kbit bitmaps> for segments with thousands of absent
+// records, <128, 512, 8 Kbit> (8 KB of LDS, many workgroups per CU) when a segment holds a few hundred.
+constexpr int CNT_RPT = 16;                            // records held per thread
+
+template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS>
 __global__ void __launch_bounds__(CNT_THREADS)
-seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count, uint64_t out_cap,
+seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count, uint64_t region_cap,
                  uint64_t *__restrict__ out_kmer, uint32_t *__restrict__ out_cnt, Counters *ctr)
 {
     __shared__ unsigned long long keys[CNT_SLOTS];
     __shared__ uint32_t cnts[CNT_SLOTS];
+    __shared__ uint32_t bm_a[CNT_BM_WORDS], bm_b[CNT_BM_WORDS];
     __shared__ uint32_t wave_sums[CNT_THREADS / 64];
     __shared__ uint32_t total;
     __shared__ unsigned long long gbase;
+    constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6;
     uint32_t n_distinct = 0, n_fail = 0;
+    // this workgroup appends to output region `region` through that region's own fill counter
+    const uint32_t region = blockIdx.x % RESULT_REGIONS;
+    unsigned long long *fill = &ctr->region_fill[region];
+    const uint64_t region_base = (uint64_t)region * region_cap;
     // persistent: a workgroup walks segments blockIdx.x, +gridDim.x, ... (launching one tiny
     // workgroup per segment cost ~50 ns of wall time each at 2^18 segments)
     for (uint64_t seg_id = blockIdx.x; seg_id < n_seg; seg_id += gridDim.x) {
-    const SegPieces sp = seg_pieces(pl, seg_id);
-    const uint32_t n = sp.total();
-    if (n == 0) continue;
-    // a value no record of this segment can take: its top T bits differ from the segment id
-    const unsigned long long EMPTY = (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
-    const uint32_t rounds = (n + CNT_SLOTS / 2 - 1) / (CNT_SLOTS / 2);
-    // small segments use a smaller power-of-two part of the table (load <= 1/2): clearing and
-    // scanning 4096 slots for a few hundred records dominated at large filters
-    uint32_t slots = 256;
-    while (slots < 2 * n && slots < (uint32_t)CNT_SLOTS) slots <<= 1;
-    const uint32_t slot_mask = slots - 1;
-    for (uint32_t r = 0; r < rounds; r++) {
-        for (uint32_t i = threadIdx.x; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
-        __syncthreads();
-        constexpr int UNROLL = 8;             // records in flight per thread (loads first, then the LDS inserts)
-        for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * CNT_THREADS) {
-            uint64_t hv[UNROLL];
-            bool mine_r[UNROLL];
+        const SegPieces sp = seg_pieces(pl, seg_id);
+        const uint32_t n = sp.total();
+        if (n == 0) continue;
+        // a value no record of this segment can take: its top T bits differ from the segment id
+        const unsigned long long EMPTY = (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
+        const uint32_t n_chunks = (n + CNT_CHUNK - 1) / CNT_CHUNK;
+        const bool single = n_chunks == 1;                 // the common case: the records stay in registers
+        uint64_t hv[CNT_RPT];
+        auto load_chunk = [&](uint32_t c) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + (uint32_t)u * CNT_THREADS + threadIdx.x;
+            for (int u = 0; u < CNT_RPT; u++) {
+                const uint32_t i = c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid;
                 hv[u] = i < n ? sp.at(i) : 0;
-                mine_r[u] = i < n;
             }
+        };
+        auto have = [&](uint32_t c, int u) -> bool { return c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid < n; };
+        // bitmap of >= 8 bits per record (<= 12 % of the unique records collide), a power of two up to 64 Kbit
+        uint32_t bm_words = 64;
+        while (bm_words * 4 < n && bm_words < (uint32_t)CNT_BM_WORDS) bm_words <<= 1;
+        const uint32_t bm_mask = bm_words * 32 - 1;
+        auto bit_of = [=](uint64_t h, uint32_t &w, uint32_t &m) {
+            const uint32_t b = (uint32_t)(h >> 20) & bm_mask;
+            w = b >> 5;
+            m = 1u << (b & 31);
+        };
+        for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
+        if (single) load_chunk(0);
+        __syncthreads();
+        // pass 1: mark
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            if (!single) load_chunk(c);
 #pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const uint64_t h = hv[u];
-                const uint32_t rr = (uint32_t)((((h >> 33) & 0x1FFF) * rounds) >> 13);
-                if (!mine_r[u] || rr != r) continue;
-                uint32_t slot = (uint32_t)(h >> 20) & slot_mask;
-                uint32_t tries = 0;
-                for (; tries < slots; tries++) {
-                    const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
-                    if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
-                    slot = (slot + 1) & slot_mask;
-                }
-                if (tries == slots) n_fail++;           // table full: host falls back to the direct family
+            for (int u = 0; u < CNT_RPT; u++) {
+                if (!have(c, u)) continue;
+                uint32_t w, m;
+                bit_of(hv[u], w, m);
+                if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
             }
         }
         __syncthreads();
-        // emit: count, scan, reserve, write
-        uint32_t mine = 0;
-        for (uint32_t s = threadIdx.x; s < slots; s += CNT_THREADS) {
-            if (keys[s] != EMPTY) { n_distinct++; if (cnts[s] >= min_count) mine++; }
+        // pass 2: classify; per-wave count of provably unique records, block count of flagged ones
+        uint32_t my_unique = 0, my_flagged = 0;
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            if (!single) load_chunk(c);
+#pragma unroll
+            for (int u = 0; u < CNT_RPT; u++) {
+                if (!have(c, u)) continue;
+                uint32_t w, m;
+                bit_of(hv[u], w, m);
+                if (bm_b[w] & m) my_flagged++; else my_unique++;
+            }
         }
-        const uint32_t ex = block_excl_scan(mine, wave_sums, &total);
-        if (threadIdx.x == 0) gbase = total ? atomicAdd(&ctr->n_emitted, (unsigned long long)total) : 0ULL;
+        const uint32_t emit_unique = min_count <= 1 ? 1u : 0u;
+        const uint32_t wave_unique = wave_total(my_unique);          // uniform per wave
+        (void)block_excl_scan(my_flagged, wave_sums, &total);
+        const uint32_t n_flagged = total;
         __syncthreads();
-        uint64_t o = gbase + ex;
-        for (uint32_t s = threadIdx.x; s < slots; s += CNT_THREADS) {
-            if (keys[s] != EMPTY && cnts[s] >= min_count) {
-                if (o < out_cap) {
-                    out_kmer[o] = unfmix64(keys[s]) ^ seed;
-                    out_cnt[o] = cnts[s];
+        // bases of the waves' unique runs: prefix over the per-wave totals
+        if ((tid & 63) == 0) wave_sums[wave] = wave_unique;
+        __syncthreads();
+        uint32_t wave_base = 0, all_unique = 0;
+#pragma unroll
+        for (int v = 0; v < CNT_THREADS / 64; v++) {
+            const uint32_t x = wave_sums[v];
+            if (v < wave) wave_base += x;
+            all_unique += x;
+        }
+        n_distinct += (tid == 0) ? all_unique : 0;
+        if (tid == 0) gbase = (emit_unique && all_unique) ? atomicAdd(fill, (unsigned long long)all_unique) : 0ULL;
+        __syncthreads();
+        // pass 3: emit the unique records, each wave a contiguous run, compacted by ballot
+        if (emit_unique && all_unique) {
+            uint64_t o = gbase + wave_base;
+            for (uint32_t c = 0; c < n_chunks; c++) {
+                if (!single) load_chunk(c);
+#pragma unroll
+                for (int u = 0; u < CNT_RPT; u++) {
+                    bool uniq = false;
+                    if (have(c, u)) {
+                        uint32_t w, m;
+                        bit_of(hv[u], w, m);
+                        uniq = !(bm_b[w] & m);
+                    }
+                    const uint64_t bal = __ballot(uniq);
+                    if (uniq) {
+                        const uint64_t pos = o + (uint64_t)popc_below(bal);
+                        if (pos < region_cap) {
+                            out_kmer[region_base + pos] = unfmix64(hv[u]) ^ seed;
+                            out_cnt[region_base + pos] = 1;
+                        } else {
+                            n_fail++;               // region full: host redoes the batch with the direct family
+                        }
+                    }
+                    o += (uint64_t)__popcll(bal);
                 }
-                o++;
+            }
+        }
+        // flagged records: exact counts in the LDS hash table, `rounds` sub-ranges at a time
+        if (n_flagged) {
+            const uint32_t rounds = (n_flagged + CNT_SLOTS / 2 - 1) / (CNT_SLOTS / 2);
+            uint32_t slots = 256;
+            while (slots < 2 * n_flagged && slots < (uint32_t)CNT_SLOTS) slots <<= 1;
+            const uint32_t slot_mask = slots - 1;
+            for (uint32_t r = 0; r < rounds; r++) {
+                __syncthreads();
+                for (uint32_t i = tid; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
+                __syncthreads();
+                for (uint32_t c = 0; c < n_chunks; c++) {
+                    if (!single) load_chunk(c);
+#pragma unroll
+                    for (int u = 0; u < CNT_RPT; u++) {
+                        if (!have(c, u)) continue;
+                        const uint64_t h = hv[u];
+                        uint32_t w, m;
+                        bit_of(h, w, m);
+                        if (!(bm_b[w] & m)) continue;
+                        const uint32_t rr = (uint32_t)((((h >> 36) & 0x3FF) * rounds) >> 10);
+                        if (rr != r) continue;
+                        uint32_t slot = (uint32_t)(h >> 8) & slot_mask;
+                        uint32_t tries = 0;
+                        for (; tries < slots; tries++) {
+                            const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
+                            if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
+                            slot = (slot + 1) & slot_mask;
+                        }
+                        if (tries == slots) n_fail++;       // table full: host falls back to the direct family
+                    }
+                }
+                __syncthreads();
+                uint32_t mine = 0;
+                for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS)
+                    if (keys[sl] != EMPTY) { n_distinct++; if (cnts[sl] >= min_count) mine++; }
+                const uint32_t ex = block_excl_scan(mine, wave_sums, &total);
+                if (tid == 0) gbase = total ? atomicAdd(fill, (unsigned long long)total) : 0ULL;
+                __syncthreads();
+                uint64_t o = gbase + ex;
+                for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS) {
+                    if (keys[sl] != EMPTY && cnts[sl] >= min_count) {
+                        if (o < region_cap) {
+                            out_kmer[region_base + o] = unfmix64(keys[sl]) ^ seed;
+                            out_cnt[region_base + o] = cnts[sl];
+                        } else {
+                            n_fail++;
+                        }
+                        o++;
+                    }
+                }
             }
         }
         __syncthreads();
-    }
     }
     n_distinct = (uint32_t)wave_sum(n_distinct);
     n_fail = (uint32_t)wave_sum(n_fail);
@@ -772,18 +878,37 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
         n_absent = e->h_ctr->n_absent;
     }
     if (st == DK_OK && n_absent) {
-        st = pool_alloc(e, n_absent * 8, (void **)&res->d_lo);
-        if (st == DK_OK) st = pool_alloc(e, n_absent * 4, (void **)&res->d_cnt);
+        // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the
+        // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each)
+        const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, p.n_seg);
+        const uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536;
+        st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
+        if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {
-            const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 12);
-            seg_count_kernel<<<cgrid, CNT_THREADS, 0, e->stream>>>(
-                list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, n_absent, res->d_lo, res->d_cnt, e->d_ctr);
+            if (n_absent / p.n_seg >= 1500) {
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 6);
+                seg_count_kernel<512, 2048, 2048><<<cgrid, 512, 0, e->stream>>>(
+                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_cnt, e->d_ctr);
+            } else {
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 32);
+                seg_count_kernel<128, 512, 256><<<cgrid, 128, 0, e->stream>>>(
+                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_cnt, e->d_ctr);
+            }
             hipError_t h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
             else stage_mark(e, "seg_count");
         }
         if (st == DK_OK) st = sync_counters(e, "bucketed count");
-        if (st == DK_OK) res->n = e->h_ctr->n_emitted;
+        if (st == DK_OK) {
+            res->n_regions = RESULT_REGIONS;
+            res->region_cap = region_cap;
+            res->n = 0;
+            for (int j = 0; j < RESULT_REGIONS; j++) {
+                res->region_n[j] = e->h_ctr->region_fill[j];
+                res->n += res->region_n[j];
+            }
+            e->h_ctr->n_emitted = res->n;
+        }
     }
     free_bufs(e, B);
     return st;

@@ -12,6 +12,7 @@ namespace dk {
 
 constexpr int DIRECT_BLOCK = 256;
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
+constexpr int RESULT_REGIONS = 32;      // output regions of the bucketed count kernel (one fill counter each)
 
 struct StreamView {
     const uint64_t *bases;
@@ -37,6 +38,7 @@ struct Counters {               // device-side statistics of one operation
     unsigned long long n_overflow;  // bucketed: records diverted to the overflow list
     unsigned long long pad[2];
     unsigned long long dbg[8];      // DK_STAMPS diagnostic builds only: per-phase cycle sums
+    unsigned long long region_fill[32];   // bucketed seg_count: entries written to each output region
 };
 
 // ---- ASCII -> packed stream ------------------------------------------------------------------

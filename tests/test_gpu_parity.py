@@ -402,6 +402,30 @@ def test_heavy_hitter_overflow_falls_back_exactly():
 
 
 @pytest.mark.parametrize("mode", MODES)
+def test_result_device_view_is_dense(mode):
+    # the bucketed count kernel fills several output regions; a device view must be one dense array
+    d = dk()
+    gcfg = d.synth_config(genome_len=150_000)
+    with make_engine(mode, k=31, filter_log2_bits=27, n_hashes=4) as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_reads(d.ReadBatch.synth(eng, gcfg, 0, 0, 15_000))
+        res = d.KmerCounter(eng).child_only(d.ReadBatch.synth(eng, gcfg, 2, 0, 15_000), ks)
+        before = res.to_host()
+        plo, phi, pcnt, n = res.device_view()
+        assert n == len(before[1]) == res.stats["n_emitted"] and plo and pcnt
+        res._host = None
+        after = res.to_host()
+        for a, b in zip(before, after):
+            assert np.array_equal(a, b)
+        import torch
+        buf = torch.empty(n, dtype=torch.int64, device="cuda")
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(plo), ctypes.c_size_t(n * 8), 3) == 0
+        assert np.array_equal(np.sort(buf.cpu().numpy().view(np.uint64)), before[1])
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_repeat_runs_are_bitwise_identical(mode):
     # atomics commute (OR / integer add): the result must not depend on scheduling
     d = dk()
