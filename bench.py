@@ -62,8 +62,9 @@ def unpack_to_ascii(bases, mask, n_reads, read_len):
 
 
 def cpu_baseline(dk, eng, kset, gcfg, args, sample_reads):
-    """Time the CPU oracle ("port": the build's C restatement, single thread) on a bounded sample
-    of the same child workload against the same filter, and cross-check the GPU on that sample."""
+    """Time the CPU oracle ("port": the build's C restatement, OpenMP over reads on the host cores
+    this process may use) on a bounded sample of the same child workload against the same filter,
+    and cross-check the GPU on that sample."""
     import numpy as np
     from oracle import orc
     filt = kset.to_host()
@@ -71,17 +72,19 @@ def cpu_baseline(dk, eng, kset, gcfg, args, sample_reads):
     bases, mask, _ = sb.download()
     seq = unpack_to_ascii(bases, mask, sample_reads, args.read_len)
     off = (np.arange(sample_reads + 1, dtype=np.uint64) * np.uint64(args.read_len)).astype(np.uint64)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, args.cpu_threads if args.cpu_threads > 0 else cores))
     t0 = time.perf_counter()
-    km, cn, st = orc.bloom_probe(filt, args.log2_bits, args.n_hashes, args.seed, args.k, True, seq, off)
+    km, cn, st = orc.bloom_probe(filt, args.log2_bits, args.n_hashes, args.seed, args.k, True, seq, off, n_threads=cores)
     dt = time.perf_counter() - t0
     res = dk.KmerCounter(eng).child_only(sb, kset)
     hi, lo, cnt = res.to_host()
     ok = bool(np.array_equal(lo, km["lo"]) and np.array_equal(hi, km["hi"]) and np.array_equal(cnt, cn))
     res.close()
     sb.close()
-    return {"value": st["n_windows"] / dt / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "port",
+    return {"value": st["n_windows"] / dt / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "port",
             "sample": f"first {sample_reads} child reads of the same workload ({st['n_windows']} windows, "
-                      f"{dt:.1f} s), oracle/dk_oracle.c single thread, same {len(filt) * 8 >> 20} MiB filter",
+                      f"{dt:.1f} s), oracle/dk_oracle.c with {cores} OpenMP thread(s), same {len(filt) * 8 >> 20} MiB filter",
             "gpu_matches_oracle_on_sample": ok}
 
 
@@ -98,7 +101,8 @@ def main():
     ap.add_argument("--n-hashes", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260313)
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "bucketed"])
-    ap.add_argument("--cpu-sample-reads", type=int, default=300_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline; 0 = all cores this process may use")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")

@@ -171,37 +171,107 @@ static int64_t rle_emit(orc_kmer *list, uint64_t n, uint32_t min_count,
     return (int64_t)nout;
 }
 
-/* spec A-6/A-9: child windows probed against the parent filter; absent ones counted */
+/* spec A-6/A-9: child windows probed against the parent filter; absent ones counted.
+ * n_threads > 1 splits the reads into contiguous ranges over OpenMP threads (each with its own
+ * absent list); the final sort + run-length encode is serial.  Results do not depend on n_threads. */
+typedef struct { orc_kmer *list; uint64_t n, cap; orc_stats st; } probe_part;
+
+static void probe_range(const uint64_t *filter, int log2_bits, int n_hashes, uint64_t seed, int k, int canonical,
+                        const uint8_t *seq, const uint64_t *offsets, uint64_t r0, uint64_t r1, uint64_t ml,
+                        probe_part *out)
+{
+    orc_kmer *km = (orc_kmer *)malloc((ml + 1) * sizeof(orc_kmer));
+    uint8_t *va = (uint8_t *)malloc(ml + 1);
+    out->cap = 1024;
+    out->n = 0;
+    out->list = (orc_kmer *)malloc(out->cap * sizeof(orc_kmer));
+    memset(&out->st, 0, sizeof out->st);
+    for (uint64_t r = r0; r < r1; r++) {
+        uint64_t l = offsets[r + 1] - offsets[r];
+        uint64_t nw = orc_read_kmers(seq + offsets[r], l, k, canonical, km, va);
+        out->st.n_reads++;
+        out->st.n_windows += nw;
+        for (uint64_t w = 0; w < nw; w++) {
+            if (!va[w]) continue;
+            out->st.n_valid++;
+            if (bloom_test(filter, orc_hash_kmer(km[w], k, seed), log2_bits, n_hashes)) continue;
+            out->st.n_absent++;
+            if (out->n == out->cap) { out->cap *= 2; out->list = (orc_kmer *)realloc(out->list, out->cap * sizeof(orc_kmer)); }
+            out->list[out->n++] = km[w];
+        }
+    }
+    free(km); free(va);
+}
+
+int64_t orc_bloom_probe_reads_mt(const uint64_t *filter, int log2_bits, int n_hashes, uint64_t seed,
+                                 int k, int canonical, uint32_t min_count,
+                                 const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
+                                 orc_kmer *out_kmers, uint32_t *out_counts, uint64_t cap,
+                                 orc_stats *stats, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    uint64_t ml = max_read_len(offsets, n_reads);
+    probe_part *parts = (probe_part *)calloc((size_t)n_threads, sizeof(probe_part));
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; t++) {
+        uint64_t r0 = n_reads * (uint64_t)t / (uint64_t)n_threads, r1 = n_reads * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        probe_range(filter, log2_bits, n_hashes, seed, k, canonical, seq, offsets, r0, r1, ml, &parts[t]);
+    }
+    /* every thread sorts its own absent list; one linear multi-way merge then counts runs */
+#pragma omp parallel for num_threads(n_threads) schedule(static, 1)
+    for (int t = 0; t < n_threads; t++) qsort(parts[t].list, parts[t].n, sizeof(orc_kmer), cmp_kmer);
+    orc_stats st = {0};
+    for (int t = 0; t < n_threads; t++) {
+        st.n_reads += parts[t].st.n_reads;
+        st.n_windows += parts[t].st.n_windows;
+        st.n_valid += parts[t].st.n_valid;
+        st.n_absent += parts[t].st.n_absent;
+    }
+    uint64_t *head = (uint64_t *)calloc((size_t)n_threads, sizeof(uint64_t));
+    int64_t nout = 0;
+    int have_cur = 0;
+    orc_kmer cur = {0, 0};
+    uint64_t cur_n = 0;
+    for (;;) {
+        int best = -1;
+        for (int t = 0; t < n_threads; t++) {
+            if (head[t] >= parts[t].n) continue;
+            if (best < 0 || cmp_kmer(&parts[t].list[head[t]], &parts[best].list[head[best]]) < 0) best = t;
+        }
+        if (best >= 0 && have_cur && cmp_kmer(&parts[best].list[head[best]], &cur) == 0) {
+            cur_n++;
+            head[best]++;
+            continue;
+        }
+        if (have_cur) {                       /* close the finished run */
+            st.n_distinct++;
+            if (cur_n >= min_count) {
+                if ((uint64_t)nout >= cap) { nout = -1; break; }
+                out_kmers[nout] = cur;
+                out_counts[nout] = cur_n > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)cur_n;
+                nout++;
+            }
+        }
+        if (best < 0) break;
+        cur = parts[best].list[head[best]++];
+        cur_n = 1;
+        have_cur = 1;
+    }
+    for (int t = 0; t < n_threads; t++) free(parts[t].list);
+    free(parts);
+    free(head);
+    if (stats) *stats = st;
+    return nout;
+}
+
 int64_t orc_bloom_probe_reads(const uint64_t *filter, int log2_bits, int n_hashes, uint64_t seed,
                               int k, int canonical, uint32_t min_count,
                               const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
                               orc_kmer *out_kmers, uint32_t *out_counts, uint64_t cap,
                               orc_stats *stats)
 {
-    uint64_t ml = max_read_len(offsets, n_reads);
-    orc_kmer *km = (orc_kmer *)malloc((ml + 1) * sizeof(orc_kmer));
-    uint8_t *va = (uint8_t *)malloc(ml + 1);
-    uint64_t lcap = 1024, ln = 0;
-    orc_kmer *list = (orc_kmer *)malloc(lcap * sizeof(orc_kmer));
-    orc_stats st = {0};
-    for (uint64_t r = 0; r < n_reads; r++) {
-        uint64_t l = offsets[r + 1] - offsets[r];
-        uint64_t nw = orc_read_kmers(seq + offsets[r], l, k, canonical, km, va);
-        st.n_reads++;
-        st.n_windows += nw;
-        for (uint64_t w = 0; w < nw; w++) {
-            if (!va[w]) continue;
-            st.n_valid++;
-            if (bloom_test(filter, orc_hash_kmer(km[w], k, seed), log2_bits, n_hashes)) continue;
-            st.n_absent++;
-            if (ln == lcap) { lcap *= 2; list = (orc_kmer *)realloc(list, lcap * sizeof(orc_kmer)); }
-            list[ln++] = km[w];
-        }
-    }
-    int64_t nout = rle_emit(list, ln, min_count, out_kmers, out_counts, cap, &st.n_distinct);
-    free(list); free(km); free(va);
-    if (stats) *stats = st;
-    return nout;
+    return orc_bloom_probe_reads_mt(filter, log2_bits, n_hashes, seed, k, canonical, min_count, seq, offsets,
+                                    n_reads, out_kmers, out_counts, cap, stats, 1);
 }
 
 /* collect all valid k-mers of a read set into a malloc'd list */

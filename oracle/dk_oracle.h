@@ -65,6 +65,13 @@ int64_t orc_bloom_probe_reads(const uint64_t *filter, int log2_bits, int n_hashe
                               orc_kmer *out_kmers, uint32_t *out_counts, uint64_t cap,
                               orc_stats *stats);
 
+/* Same result with the reads split over n_threads OpenMP threads (bench.py's cpu_baseline). */
+int64_t orc_bloom_probe_reads_mt(const uint64_t *filter, int log2_bits, int n_hashes, uint64_t seed,
+                                 int k, int canonical, uint32_t min_count,
+                                 const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
+                                 orc_kmer *out_kmers, uint32_t *out_counts, uint64_t cap,
+                                 orc_stats *stats, int n_threads);
+
 /* Exact-set semantics (what a HashSet-based KmerSet would give): child k-mers
  * absent from the union of the parent reads.  Same output conventions as the Bloom probe. */
 int64_t orc_exact_child_only(int k, int canonical, uint32_t min_count,

@@ -65,6 +65,10 @@ def lib():
         L.orc_bloom_probe_reads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                             C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(OrcStats)]
+        L.orc_bloom_probe_reads_mt.restype = C.c_int64
+        L.orc_bloom_probe_reads_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                               C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
+                                               C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(OrcStats), C.c_int]
         L.orc_exact_child_only.restype = C.c_int64
         L.orc_exact_child_only.argtypes = [C.c_int, C.c_int, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_uint64,
@@ -142,14 +146,14 @@ def n_windows(offsets, k):
     return int(np.maximum(ln - k + 1, 0).sum())
 
 
-def bloom_probe(filt, log2_bits, n_hashes, seed, k, canonical, seq, offsets, min_count=1):
+def bloom_probe(filt, log2_bits, n_hashes, seed, k, canonical, seq, offsets, min_count=1, n_threads=1):
     cap = max(1, n_windows(offsets, k))
     km = np.zeros(cap, dtype=KMER_DT)
     cn = np.zeros(cap, dtype=np.uint32)
     st = OrcStats()
-    n = lib().orc_bloom_probe_reads(_ptr(filt), log2_bits, n_hashes, C.c_uint64(seed), k, int(canonical),
-                                    min_count, _ptr(seq), _ptr(offsets), len(offsets) - 1,
-                                    _ptr(km), _ptr(cn), cap, C.byref(st))
+    n = lib().orc_bloom_probe_reads_mt(_ptr(filt), log2_bits, n_hashes, C.c_uint64(seed), k, int(canonical),
+                                       min_count, _ptr(seq), _ptr(offsets), len(offsets) - 1,
+                                       _ptr(km), _ptr(cn), cap, C.byref(st), n_threads)
     assert n >= 0
     return km[:n].copy(), cn[:n].copy(), st.as_dict()
 

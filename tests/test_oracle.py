@@ -163,6 +163,21 @@ def test_exact_is_superset_of_bloom(rng):
     assert all(e[x] == b[x] for x in b)
 
 
+def test_multithreaded_probe_equals_single_thread(rng):
+    parents, child = related_trio(rng, genome_len=3000, n_reads=200, read_len=100)
+    pseq, poff = orc.concat_reads(parents)
+    cseq, coff = orc.concat_reads(child + child[:50])
+    f = orc.new_filter(20)
+    orc.bloom_insert(f, 20, 3, 5, 27, True, pseq, poff)
+    ref = orc.bloom_probe(f, 20, 3, 5, 27, True, cseq, coff, min_count=1, n_threads=1)
+    for t in (2, 3, 8):
+        got = orc.bloom_probe(f, 20, 3, 5, 27, True, cseq, coff, min_count=1, n_threads=t)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[2] == ref[2]
+    ref2 = orc.bloom_probe(f, 20, 3, 5, 27, True, cseq, coff, min_count=2, n_threads=1)
+    got2 = orc.bloom_probe(f, 20, 3, 5, 27, True, cseq, coff, min_count=2, n_threads=4)
+    assert np.array_equal(got2[0], ref2[0]) and np.array_equal(got2[1], ref2[1]) and len(ref2[0]) < len(ref[0])
+
+
 def test_count_reads_is_probe_of_empty_filter(rng):
     reads = random_reads(rng, 10, 30, 80, n_rate=0.01) * 2
     seq, off = orc.concat_reads(reads)
