@@ -102,6 +102,26 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
     return wave_sums[wave] + inc - v;
 }
 
+// Overflow list: records that do not fit their piece / segment region (heavy-hitter k-mers such as
+// poly-A, or skew beyond the capacity slack) are appended here instead of being dropped, and are
+// handled exactly afterwards: OR-ed into the filter one by one (insert), or probed one by one and
+// handed to seg_count as an extra per-segment list (probe).  Only if this list overflows too is the
+// batch redone by the direct family.
+struct OvfList {
+    uint64_t *recs;
+    unsigned long long *count;     // &Counters::n_ovf
+    uint64_t cap;
+};
+
+__device__ __forceinline__ void ovf_append(const OvfList &ovf, bool pred, uint64_t h, uint32_t &n_dropped)
+{
+    const uint64_t slot = wave_append(pred, ovf.count);
+    if (pred) {
+        if (slot < ovf.cap) ovf.recs[slot] = h;
+        else n_dropped++;
+    }
+}
+
 // ---- shared multisplit tail ------------------------------------------------------------------------
 // A tile's records sit in registers (hs = hash, rk = rank inside its bin from the LDS count).
 // Wave 0 turns the per-bin counts into tile offsets and advances the workgroup's running cursors
@@ -133,7 +153,7 @@ template <int THREADS, int PER_THREAD, class BinOf>
 __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &L, const uint64_t (&hs)[PER_THREAD],
                                                  const uint32_t (&rk)[PER_THREAD], uint32_t valid, int nbins, BinOf bin_of,
                                                  uint64_t bin_base, uint64_t bin_stride, uint64_t piece_off,
-                                                 uint32_t cap, uint64_t *__restrict__ out,
+                                                 uint32_t cap, uint64_t *__restrict__ out, const OvfList &ovf,
                                                  uint32_t &n_records, uint32_t &n_overflow, Stamps &st)
 {
     const int tid = (int)threadIdx.x;
@@ -177,7 +197,7 @@ __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &
         const uint32_t bin = bin_of(h);
         const uint32_t idx = i + L.delta[bin];
         if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = h;
-        else n_overflow++;
+        ovf_append(ovf, idx >= cap, h, n_overflow);
     }
     if (tid == 0) n_records += total;
     st.mark(3);
@@ -203,7 +223,7 @@ __device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD> 
 template <int THREADS, int PER_THREAD, int MIN_WAVES>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
-                 uint64_t *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles, Counters *ctr)
+                 uint64_t *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles, OvfList ovf, Counters *ctr)
 {
     constexpr int TILE = THREADS * PER_THREAD;
     static_assert(PER_THREAD % 8 == 0 && PER_THREAD <= 16, "a thread's positions must stay inside two bases words");
@@ -267,7 +287,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();                                   // A
-        multisplit_flush(L, hs, rk, valid, nbins, bin_of, 0, G * capw, w * capw, capw, out, n_records, n_overflow, st);
+        multisplit_flush(L, hs, rk, valid, nbins, bin_of, 0, G * capw, w * capw, capw, out, ovf, n_records, n_overflow, st);
     }
     st.flush(ctr, 0);
     multisplit_finish(L, nbins, 0, (uint32_t)G, (uint32_t)w, capw, cnt1);
@@ -285,7 +305,7 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, uint64_t *__restrict__ out,
-              uint32_t *__restrict__ cursor2, Counters *ctr)
+              uint32_t *__restrict__ cursor2, OvfList ovf, Counters *ctr)
 {
     constexpr int TILE = THREADS * PER_THREAD;
     __shared__ SplitLds<THREADS, PER_THREAD> L;
@@ -355,7 +375,7 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
         const uint32_t bin = bin_of(h);
         const uint32_t idx = i + L.delta[bin];
         if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = h;
-        else n_overflow++;
+        ovf_append(ovf, idx >= cap2, h, n_overflow);
     }
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
@@ -369,15 +389,22 @@ struct PieceList {
     const uint32_t *cnt;
     uint32_t n_pieces;     // <= MAX_R
     uint32_t piece_cap;
+    // optional extra records per segment (overflow records that were absent), CSR over segments:
+    // segment s owns extra[extra_off[s] .. extra_off[s + 1])
+    const uint64_t *extra;
+    const uint32_t *extra_off;
 };
 
 struct SegPieces {
-    uint32_t start[MAX_R + 1];     // prefix sums of the piece sizes; start[n_pieces] = total
+    uint32_t start[MAX_R + 1];     // prefix sums of the piece sizes; start[MAX_R] = records in the pieces
     const uint64_t *base;          // first piece of the segment
     uint32_t piece_cap;
-    __device__ __forceinline__ uint32_t total() const { return start[MAX_R]; }
+    const uint64_t *extra;         // extra records of the segment (or nullptr)
+    uint32_t n_extra;
+    __device__ __forceinline__ uint32_t total() const { return start[MAX_R] + n_extra; }
     __device__ __forceinline__ uint64_t at(uint32_t i) const
     {
+        if (i >= start[MAX_R]) return extra[i - start[MAX_R]];
         uint32_t r = 0, st = 0;
 #pragma unroll
         for (int q = 1; q < MAX_R; q++)
@@ -401,6 +428,13 @@ __device__ __forceinline__ SegPieces seg_pieces(const PieceList &pl, uint64_t se
         }
     }
     sp.start[MAX_R] = acc;
+    sp.extra = nullptr;
+    sp.n_extra = 0;
+    if (pl.extra) {
+        const uint32_t o0 = pl.extra_off[seg_id], o1 = pl.extra_off[seg_id + 1];
+        sp.extra = pl.extra + o0;
+        sp.n_extra = o1 - o0;
+    }
     return sp;
 }
 
@@ -632,15 +666,20 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
                 }
             }
         }
-        // flagged records: exact counts in the LDS hash table, `rounds` sub-ranges at a time
+        // Flagged records: exact counts in the LDS hash table, one sub-range of the key space per
+        // round.  The number of rounds starts from a guess (8 copies per key) and a round whose keys
+        // do not fit is split in four and redone -- nothing of it has been emitted yet -- so a segment
+        // holding a million copies of one k-mer costs one round, not a thousand.
         if (n_flagged) {
-            const uint32_t rounds = (n_flagged + CNT_SLOTS / 2 - 1) / (CNT_SLOTS / 2);
             uint32_t slots = 256;
             while (slots < 2 * n_flagged && slots < (uint32_t)CNT_SLOTS) slots <<= 1;
             const uint32_t slot_mask = slots - 1;
-            for (uint32_t r = 0; r < rounds; r++) {
+            uint32_t rounds = (n_flagged + 4 * slots - 1) / (4 * slots);
+            uint32_t r = 0;
+            while (r < rounds) {
                 __syncthreads();
                 for (uint32_t i = tid; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
+                if (tid == 0) total = 0;                       // doubles as the "round does not fit" flag
                 __syncthreads();
                 for (uint32_t c = 0; c < n_chunks; c++) {
                     if (!single) load_chunk(c);
@@ -651,19 +690,25 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
                         uint32_t w, m;
                         bit_of(h, w, m);
                         if (!(bm_b[w] & m)) continue;
-                        const uint32_t rr = (uint32_t)((((h >> 36) & 0x3FF) * rounds) >> 10);
+                        const uint32_t rr = (uint32_t)((((h >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20);
                         if (rr != r) continue;
                         uint32_t slot = (uint32_t)(h >> 8) & slot_mask;
                         uint32_t tries = 0;
-                        for (; tries < slots; tries++) {
+                        for (; tries < 64; tries++) {
                             const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
                             if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
                             slot = (slot + 1) & slot_mask;
                         }
-                        if (tries == slots) n_fail++;       // table full: host falls back to the direct family
+                        if (tries == 64) total = 1;            // too crowded: split this round
                     }
                 }
                 __syncthreads();
+                if (total) {
+                    if (rounds >= (1u << 18)) { n_fail++; r = rounds; break; }   // cannot split further: redo on the direct family
+                    rounds *= 4;
+                    r *= 4;
+                    continue;
+                }
                 uint32_t mine = 0;
                 for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS)
                     if (keys[sl] != EMPTY) { n_distinct++; if (cnts[sl] >= min_count) mine++; }
@@ -682,6 +727,7 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
                         o++;
                     }
                 }
+                r++;
             }
         }
         __syncthreads();
@@ -691,6 +737,82 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
     if (lane_id() == 0) {
         if (n_distinct) atomicAdd(&ctr->n_distinct, (unsigned long long)n_distinct);
         if (n_fail) atomicAdd(&ctr->n_overflow, (unsigned long long)n_fail);
+    }
+}
+
+// ---- overflow records: exact one-by-one handling (rare path) -------------------------------------------
+__device__ __forceinline__ bool ovf_filter_op(unsigned long long *filter, uint64_t h, int log2_blocks, int n_hashes, bool set)
+{
+    unsigned long long *blk = filter + bloom_block(h, log2_blocks) * 8;
+    const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
+    bool all = true;
+    for (int j = 0; j < n_hashes; j++) {
+        const uint32_t bit = (a + (uint32_t)j * d) & 511;
+        const unsigned long long m = 1ULL << (bit & 63);
+        if (set) { if (!(blk[bit >> 6] & m)) atomicOr(&blk[bit >> 6], m); }
+        else all = all && (blk[bit >> 6] & m);
+    }
+    return all;
+}
+
+// OR the overflow records into the filter (after seg_insert has written its segments back)
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+ovf_insert_kernel(unsigned long long *filter, OvfList ovf, int log2_blocks, int n_hashes)
+{
+    unsigned long long n = *ovf.count;
+    if (n > ovf.cap) n = ovf.cap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        ovf_filter_op(filter, ovf.recs[i], log2_blocks, n_hashes, true);
+}
+
+// Probe the overflow records (filter == nullptr: every record counts as absent); absent ones are
+// appended to `miss` and tallied per segment for the CSR build.
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+ovf_probe_kernel(unsigned long long *filter, OvfList ovf, int log2_blocks, int n_hashes, int T,
+                 uint64_t *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
+{
+    unsigned long long n = *ovf.count;
+    if (n > ovf.cap) n = ovf.cap;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (n + 63) & ~63ULL;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool have = i < n;
+        const uint64_t h = have ? ovf.recs[i] : 0;
+        const bool absent = have && (filter ? !ovf_filter_op(filter, h, log2_blocks, n_hashes, false) : true);
+        const uint64_t slot = wave_append(absent, &ctr->n_ovf_miss);
+        if (absent) {
+            miss[slot] = h;
+            atomicAdd(&seg_hist[h >> (64 - T)], 1u);
+        }
+    }
+}
+
+// exclusive scan of seg_hist[n] into off[n + 1] by one workgroup (n <= 2^21)
+__global__ void __launch_bounds__(1024)
+ovf_scan_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ off, uint32_t n)
+{
+    __shared__ uint32_t wave_sums[16];
+    __shared__ uint32_t total;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += hist[i];
+    uint32_t run = block_excl_scan(sum, wave_sums, &total);
+    for (uint32_t i = lo; i < hi; i++) { off[i] = run; run += hist[i]; }
+    if (threadIdx.x == 0) off[n] = total;
+}
+
+// place the absent overflow records into their segment's slice
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+ovf_scatter_kernel(const uint64_t *__restrict__ miss, uint64_t n, int T, const uint32_t *__restrict__ off,
+                   uint32_t *fill, uint64_t *__restrict__ extra)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = miss[i];
+        const uint64_t seg = h >> (64 - T);
+        extra[off[seg] + atomicAdd(&fill[seg], 1u)] = h;
     }
 }
 
@@ -758,6 +880,10 @@ struct BucketBufs {
     uint64_t *a = nullptr, *b = nullptr;      // level-1 pieces (later: absent lists) / segment regions
     uint32_t *cnt = nullptr;                  // cnt1 [p1 * G] | cursor2 [n_seg] | miss_cnt [n_seg]
     uint32_t *cnt1 = nullptr, *cursor2 = nullptr, *miss_cnt = nullptr;
+    uint64_t *ovf = nullptr;                  // overflow records
+    uint64_t ovf_cap = 0;
+    uint64_t *ovf_miss = nullptr, *extra = nullptr;   // probe: absent overflow records, then sorted by segment
+    uint32_t *extra_idx = nullptr;            // seg_hist [n_seg] | extra_off [n_seg + 1] | fill [n_seg]
 };
 
 inline void free_bufs(dk_engine *e, BucketBufs &B)
@@ -765,9 +891,14 @@ inline void free_bufs(dk_engine *e, BucketBufs &B)
     pool_free(e, B.a);
     pool_free(e, B.b);
     pool_free(e, B.cnt);
+    pool_free(e, B.ovf);
+    pool_free(e, B.ovf_miss);
+    pool_free(e, B.extra);
+    pool_free(e, B.extra_idx);
 }
 
-// scan_part + repart: afterwards B.b / B.cursor2 hold every record of the batch grouped by segment
+// scan_part + repart: afterwards B.b / B.cursor2 hold every record of the batch grouped by segment,
+// except the records that did not fit, which are in B.ovf (Counters::n_ovf of them)
 inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p, BucketBufs &B)
 {
     const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
@@ -779,7 +910,10 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     B.cnt1 = B.cnt;
     B.cursor2 = B.cnt + n1;
     B.miss_cnt = B.cursor2 + p.n_seg;
+    B.ovf_cap = std::max<uint64_t>(1ULL << 20, p.n_max / 8);
+    DK_TRY(pool_alloc(e, B.ovf_cap * 8, (void **)&B.ovf));
     DK_HIP(e, hipMemsetAsync(B.cursor2, 0, p.n_seg * 4, e->stream));
+    const OvfList ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
 
     StreamView sv;
     sv.bases = r->d_bases;
@@ -790,7 +924,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     const uint32_t n_tiles = (uint32_t)((r->n_bases + p.tile - 1) / p.tile);
 #define DK_SCAN_LAUNCH(TH, PT, W)                                                                                  \
     scan_part_kernel<TH, PT, W><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
-                                                           p.b1, p.capw, B.a, B.cnt1, n_tiles, e->d_ctr)
+                                                           p.b1, p.capw, B.a, B.cnt1, n_tiles, ovf, e->d_ctr)
     switch (scan_variant()) {
     case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
     case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
@@ -804,7 +938,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     do {                                                                                                  \
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                             \
-            B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, e->d_ctr);                  \
+            B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, ovf, e->d_ctr);             \
     } while (0)
     static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
     switch (rv) {
@@ -830,8 +964,8 @@ inline dk_status sync_counters(dk_engine *e, const char *what)
     return DK_OK;
 }
 
-// Returns DK_ERR_OVERFLOW when a piece overflowed: the caller then runs the direct family on the
-// whole batch, which is exact (OR is idempotent, so records already inserted do no harm).
+// Returns DK_ERR_OVERFLOW when even the overflow list overflowed: the caller then runs the direct
+// family on the whole batch, which is exact (OR is idempotent, records already inserted do no harm).
 inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
 {
     BucketPlan p;
@@ -839,14 +973,22 @@ inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
     BucketBufs B;
     dk_status st = bucketed_partition(e, r, p, B);
     if (st == DK_OK) {
-        const PieceList pl{B.b, B.cursor2, 1, p.cap2};
+        const PieceList pl{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
         seg_insert_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
             s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
         hipError_t h = hipGetLastError();
+        if (h == hipSuccess) {
+            stage_mark(e, "seg_insert");
+            // overflow records (normally none): the kernel reads their number from device memory
+            const OvfList ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+            ovf_insert_kernel<<<e->n_cu * 2, DIRECT_BLOCK, 0, e->stream>>>(
+                s->d_words, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes);
+            h = hipGetLastError();
+        }
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_insert launch failed: %s", hipGetErrorString(h));
-        else stage_mark(e, "seg_insert");
     }
     if (st == DK_OK) st = sync_counters(e, "bucketed insert");
+    if (st == DK_OK && e->h_ctr->n_ovf) stage_mark(e, "ovf_insert");
     free_bufs(e, B);
     return st;
 }
@@ -857,7 +999,7 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
     if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs B;
     dk_status st = bucketed_partition(e, r, p, B);
-    PieceList list{B.b, B.cursor2, 1, p.cap2};
+    PieceList list{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
         seg_probe_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
@@ -865,23 +1007,62 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
         else stage_mark(e, "seg_probe");
-        list = PieceList{B.a, B.miss_cnt, 1, miss_cap};
+        list = PieceList{B.a, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
     }
     if (st == DK_OK) st = sync_counters(e, "bucketed probe");
     uint64_t n_absent = 0;
     if (st == DK_OK) {
-        if (!s) {            // KmerCounter semantics: every valid k-mer is counted
-            e->h_ctr->n_absent = e->h_ctr->n_valid;
-            hipError_t h = hipMemcpyAsync(&e->d_ctr->n_absent, &e->h_ctr->n_valid, 8, hipMemcpyHostToDevice, e->stream);
-            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "counter update failed: %s", hipGetErrorString(h));
-        }
+        if (!s) e->h_ctr->n_absent = e->h_ctr->n_valid - e->h_ctr->n_ovf;   // KmerCounter: every record in a segment counts
         n_absent = e->h_ctr->n_absent;
+    }
+    // overflow records (normally none): probe them one by one, sort the absent ones by segment (CSR)
+    // and hand them to seg_count as an extra list of their segment
+    if (st == DK_OK && e->h_ctr->n_ovf) {
+        const uint64_t n_ovf = e->h_ctr->n_ovf;
+        st = pool_alloc(e, n_ovf * 8, (void **)&B.ovf_miss);
+        if (st == DK_OK) st = pool_alloc(e, n_ovf * 8, (void **)&B.extra);
+        if (st == DK_OK) st = pool_alloc(e, (3 * p.n_seg + 1) * 4, (void **)&B.extra_idx);
+        hipError_t h = hipSuccess;
+        if (st == DK_OK) {
+            uint32_t *hist = B.extra_idx, *off = hist + p.n_seg, *fill = off + p.n_seg + 1;
+            const OvfList ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+            h = hipMemsetAsync(B.extra_idx, 0, (3 * p.n_seg + 1) * 4, e->stream);
+            if (h == hipSuccess) {
+                ovf_probe_kernel<<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    s ? s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes, p.T,
+                    B.ovf_miss, hist, e->d_ctr);
+                ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)p.n_seg);
+                h = hipGetLastError();
+            }
+            if (h == hipSuccess) {
+                stage_mark(e, "ovf_probe");
+                st = sync_counters(e, "overflow probe");
+            } else {
+                st = fail(e, DK_ERR_HIP, "overflow probe failed: %s", hipGetErrorString(h));
+            }
+            if (st == DK_OK && e->h_ctr->n_ovf_miss) {
+                const uint64_t n_om = e->h_ctr->n_ovf_miss;
+                ovf_scatter_kernel<<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    B.ovf_miss, n_om, p.T, off, fill, B.extra);
+                h = hipGetLastError();
+                if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow scatter failed: %s", hipGetErrorString(h));
+                list.extra = B.extra;
+                list.extra_off = off;
+                n_absent += n_om;
+            }
+        }
+    }
+    if (st == DK_OK) {
+        e->h_ctr->n_absent = n_absent;           // dk_probe reports it; keep the device copy in step
+        hipError_t h = hipMemcpyAsync(&e->d_ctr->n_absent, &e->h_ctr->n_absent, 8, hipMemcpyHostToDevice, e->stream);
+        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "counter update failed: %s", hipGetErrorString(h));
     }
     if (st == DK_OK && n_absent) {
         // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the
-        // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each)
+        // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
+        // overflow records may all sit in one segment, hence the extra room for them
         const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, p.n_seg);
-        const uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536;
+        const uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536 + e->h_ctr->n_ovf_miss;
         st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
         if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {

@@ -36,7 +36,8 @@ struct Counters {               // device-side statistics of one operation
     unsigned long long n_distinct;
     unsigned long long n_emitted;
     unsigned long long n_overflow;  // bucketed: records diverted to the overflow list
-    unsigned long long pad[2];
+    unsigned long long n_ovf;       // bucketed: records appended to the overflow list
+    unsigned long long n_ovf_miss;  // bucketed: overflow records absent from the filter
     unsigned long long dbg[8];      // DK_STAMPS diagnostic builds only: per-phase cycle sums
     unsigned long long region_fill[32];   // bucketed seg_count: entries written to each output region
 };

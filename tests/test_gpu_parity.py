@@ -379,9 +379,10 @@ def test_two_level_partition_large_filter(log2_bits):
         assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
 
 
-def test_heavy_hitter_overflow_falls_back_exactly():
-    # one k-mer repeated far beyond its segment's capacity overflows a bin; the engine must
-    # detect it and redo the batch with the direct family, with identical results
+def test_heavy_hitter_overflow_is_handled_exactly():
+    # one k-mer repeated far beyond its segment's capacity overflows its region; the overflow records
+    # are OR-ed / probed one by one and counted with their segment, with identical results and
+    # without redoing the batch on the direct family
     d = dk()
     k = 21
     reads = ["A" * 150] * 4000 + ["ACGTTGCATGCCGATAGCTAGCTAGGATCGATCGATTAGC" * 3] * 10
@@ -389,16 +390,43 @@ def test_heavy_hitter_overflow_falls_back_exactly():
     with make_engine("bucketed", k=k, filter_log2_bits=24, n_hashes=4, seed=5) as eng:
         ks = d.KmerSet(eng)
         ks.insert_sequences(reads[:2000])
-        assert "overflow_redo" in [n for n, _ in eng.timings()["stages"]]
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert "ovf_insert" in names and "overflow_redo" not in names
         f = orc.new_filter(24)
         s2, o2 = orc.concat_reads(reads[:2000])
         orc.bloom_insert(f, 24, 4, 5, k, True, s2, o2)
         assert np.array_equal(ks.to_host(), f)
+        # KmerCounter over everything: 520 000 copies of poly-A land in one segment
         res = d.KmerCounter(eng).count_sequences(reads)
-        assert "overflow_redo" in [n for n, _ in eng.timings()["stages"]]
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert "ovf_probe" in names and "overflow_redo" not in names
         km, cn, st = orc.count_reads(k, True, seq, off)
         assert_result_equals(res, km, cn)
         assert int(cn.max()) == 4000 * 130
+        assert res.stats["n_absent"] == st["n_valid"] and res.stats["n_distinct"] == st["n_distinct"]
+        # membership pass: the heavy hitter is present in the filter, a second one is not
+        child = ["A" * 150] * 3000 + ["C" * 150] * 3000 + reads[-10:]
+        cseq, coff = orc.concat_reads(child)
+        res2 = d.KmerCounter(eng).child_only(d.ReadBatch.from_sequences(eng, child), ks)
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert "ovf_probe" in names and "overflow_redo" not in names
+        km2, cn2, st2 = orc.bloom_probe(f, 24, 4, 5, k, True, cseq, coff)
+        assert_result_equals(res2, km2, cn2)
+        assert res2.stats["n_absent"] == st2["n_absent"] and int(cn2.max()) == 3000 * 130
+
+
+def test_min_count_with_overflow_records():
+    d = dk()
+    k = 25
+    child = ["G" * 120] * 2500 + ["ACGTTGCATGCCGATAGCTAGCTAGGATCGATCGATTAGC" * 3] * 2 + ["TTGACCATGCAATGCATGCCGGATAGCTAGCATCG"]
+    seq, off = orc.concat_reads(child)
+    with make_engine("bucketed", k=k, filter_log2_bits=23, n_hashes=3, seed=8, min_count=2) as eng:
+        ks = d.KmerSet(eng)
+        res = d.KmerCounter(eng).child_only(d.ReadBatch.from_sequences(eng, child), ks)
+        f = orc.new_filter(23)
+        km, cn, st = orc.bloom_probe(f, 23, 3, 8, k, True, seq, off, min_count=2)
+        assert_result_equals(res, km, cn)
+        assert res.stats["n_distinct"] == st["n_distinct"] > len(km)
 
 
 @pytest.mark.parametrize("mode", MODES)
