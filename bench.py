@@ -49,18 +49,6 @@ def stage_algorithmic_bytes(stage, st, filter_bytes, read_len, k, geom=None):
     return table.get(stage)
 
 
-def unpack_to_ascii(bases, mask, n_reads, read_len):
-    """packed dk_reads words (fixed-length reads + separators) -> uint8 ASCII [n_reads*read_len]"""
-    import numpy as np
-    n = n_reads * (read_len + 1)
-    p = np.arange(n, dtype=np.int64)
-    codes = (bases[p >> 5] >> (62 - 2 * (p & 31)).astype(np.uint64)) & np.uint64(3)
-    flags = (mask[p >> 6] >> (63 - (p & 63)).astype(np.uint64)) & np.uint64(1)
-    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[codes.astype(np.int64)]
-    seq[flags.astype(bool)] = ord("N")
-    return np.ascontiguousarray(seq.reshape(n_reads, read_len + 1)[:, :read_len]).reshape(-1)
-
-
 def cpu_baseline(dk, eng, kset, gcfg, args, sample_reads):
     """Time the CPU oracle ("port": the build's C restatement, OpenMP over reads on the host cores
     this process may use) on a bounded sample of the same child workload against the same filter,
@@ -70,8 +58,7 @@ def cpu_baseline(dk, eng, kset, gcfg, args, sample_reads):
     filt = kset.to_host()
     sb = dk.ReadBatch.synth(eng, gcfg, 2, 0, sample_reads)
     bases, mask, _ = sb.download()
-    seq = unpack_to_ascii(bases, mask, sample_reads, args.read_len)
-    off = (np.arange(sample_reads + 1, dtype=np.uint64) * np.uint64(args.read_len)).astype(np.uint64)
+    seq, off = orc.unpack_fixed(bases, mask, sample_reads, args.read_len)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # a one-GPU box grants this job a 16-core CPU share whatever the affinity mask says
     cores = max(1, min(cores, args.cpu_threads if args.cpu_threads > 0 else 16))
@@ -102,7 +89,7 @@ def main():
     ap.add_argument("--n-hashes", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260313)
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "bucketed"])
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=6_000_000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline; 0 = min(cores this process may use, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

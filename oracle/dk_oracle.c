@@ -359,6 +359,24 @@ uint64_t orc_pack_reads(const uint8_t *seq, const uint64_t *offsets, uint64_t n_
     return p;
 }
 
+/* inverse of the packer for fixed-length reads (bench.py: the GPU generates the sample, the oracle
+ * reads it back as ASCII): out[r * read_len + j] for read r, position j; separators are skipped */
+void orc_unpack_fixed(const uint64_t *bases, const uint64_t *mask, uint64_t n_reads, uint32_t read_len,
+                      uint8_t *out)
+{
+    static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t)n_reads; r++) {
+        uint64_t p = (uint64_t)r * (read_len + 1);
+        uint8_t *o = out + (uint64_t)r * read_len;
+        for (uint32_t j = 0; j < read_len; j++, p++) {
+            const int flag = (int)((mask[p >> 6] >> (63 - (p & 63))) & 1);
+            const int code = (int)((bases[p >> 5] >> (62 - 2 * (p & 31))) & 3);
+            o[j] = flag ? 'N' : (uint8_t)ACGT[code];
+        }
+    }
+}
+
 /* ---- synthetic trio generator -------------------------------------- */
 static inline uint64_t splitmix(uint64_t x)
 {

@@ -93,6 +93,10 @@ int64_t orc_count_reads(int k, int canonical,
 uint64_t orc_pack_reads(const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
                         uint64_t *bases, uint64_t *mask);
 
+/* packed fixed-length reads -> ASCII (n_reads * read_len bytes) */
+void orc_unpack_fixed(const uint64_t *bases, const uint64_t *mask, uint64_t n_reads, uint32_t read_len,
+                      uint8_t *out);
+
 /* Synthetic trio generator (spec: DESIGN.md section 7; counter-based, stateless).
  * sample: 0 = parent 1, 1 = parent 2, 2 = child.  Writes read_len ASCII bytes. */
 typedef struct {

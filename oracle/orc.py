@@ -79,6 +79,8 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(OrcStats)]
         L.orc_pack_reads.restype = C.c_uint64
         L.orc_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_unpack_fixed.restype = None
+        L.orc_unpack_fixed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
         L.orc_synth_read.restype = None
         L.orc_synth_read.argtypes = [C.POINTER(OrcSynthCfg), C.c_int, C.c_uint64, C.c_void_p]
         L.orc_synth_mix.restype = C.c_uint64
@@ -188,6 +190,14 @@ def pack_reads(seq, offsets):
     t = lib().orc_pack_reads(_ptr(seq), _ptr(offsets), n_reads, _ptr(bases), _ptr(mask))
     assert t == total
     return bases[: (total + 31) // 32], mask[: (total + 63) // 64], total
+
+
+def unpack_fixed(bases, mask, n_reads, read_len):
+    """packed dk_reads words of fixed-length reads -> (uint8 ASCII [n_reads*read_len], offsets)"""
+    out = np.zeros(n_reads * read_len, dtype=np.uint8)
+    lib().orc_unpack_fixed(_ptr(bases), _ptr(mask), n_reads, read_len, _ptr(out))
+    offsets = (np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(read_len)).astype(np.uint64)
+    return out, offsets
 
 
 def synth_cfg(seed=20260313, genome_len=50_000, read_len=150, snv_rate=1e-3, denovo_rate=None,

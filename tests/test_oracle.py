@@ -147,6 +147,14 @@ def test_pack_reads_matches_pyref(rng):
     assert n == rn and list(map(int, b)) == rb and list(map(int, m)) == rm
 
 
+def test_unpack_fixed_inverts_pack(rng):
+    reads = random_reads(rng, 40, 75, 75, n_rate=0.05)
+    seq, off = orc.concat_reads(reads)
+    b, m, n = orc.pack_reads(seq, off)
+    out, o2 = orc.unpack_fixed(b, m, 40, 75)
+    assert bytes(out).decode() == "".join(reads).upper() and np.array_equal(o2, off)
+
+
 def test_exact_is_superset_of_bloom(rng):
     # spec A-6 invariant: Bloom negatives are exact, so bloom child-only is a subset of exact child-only
     parents = random_reads(rng, 150, 200, 200)
