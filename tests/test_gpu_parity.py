@@ -470,3 +470,71 @@ def test_repeat_runs_are_bitwise_identical(mode):
                          hashlib.sha256(lo.tobytes() + cnt.tobytes()).hexdigest()))
             ks.close()
         assert outs[0] == outs[1] == outs[2]
+
+
+# ---- BASELINE.json configs[1] at FULL size: size-independent properties ---------------------------------
+
+def _result_checksum(res):
+    """order-independent digest of a (k-mer, count) table: wrapped sums of mixed keys"""
+    hi, lo, cnt = res.to_host(sort=False)
+    with np.errstate(over="ignore"):
+        mixed = (lo ^ (lo >> np.uint64(29))) * np.uint64(0x9E3779B97F4A7C15)
+        return (int(len(lo)), int(cnt.astype(np.uint64).sum()),
+                int(mixed.sum(dtype=np.uint64)), int((mixed * cnt.astype(np.uint64)).sum(dtype=np.uint64)))
+
+
+@pytest.mark.timeout(900)
+def test_full_size_configs1_properties():
+    """k=31, 12.8 M x 150 bp reads per sample, 2^34-bit filter (the bench workload).  The oracle cannot
+    run this size in seconds, so the checks are properties: no false negatives, idempotence,
+    union-of-shards == whole, and agreement of the two independent kernel families."""
+    d = dk()
+    n_reads, k, log2_bits = 12_800_000, 31, 34
+    gcfg = d.synth_config(genome_len=64 << 20)
+    with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=20260313, mode="bucketed") as eb:
+        ks = d.KmerSet(eb)
+        p0 = d.ReadBatch.synth(eb, gcfg, 0, 0, n_reads)
+        st0 = ks.insert_reads(p0)
+        assert [n for n, _ in eb.timings()["stages"]] == ["scan_part", "repart", "seg_insert"]
+        assert st0["n_windows"] == n_reads * 120 and 0.99 * st0["n_windows"] < st0["n_valid"] < st0["n_windows"]
+        pop0 = ks.popcount()
+        # idempotence of OR: inserting the same batch again changes nothing
+        ks.insert_reads(p0)
+        assert ks.popcount() == pop0
+        # union of shards == whole: the same parent inserted as two half batches into a second filter
+        ks2 = d.KmerSet(eb)
+        ks2.insert_reads(d.ReadBatch.synth(eb, gcfg, 0, 0, n_reads // 2))
+        ks2.insert_reads(d.ReadBatch.synth(eb, gcfg, 0, n_reads // 2, n_reads - n_reads // 2))
+        assert ks2.popcount() == pop0
+        a, b = ks.to_host(), ks2.to_host()
+        assert np.array_equal(a, b)
+        del a, b
+        ks2.close()
+        # no false negatives: every k-mer of the inserted reads is present
+        self_probe = d.KmerCounter(eb).child_only(p0, ks)
+        assert self_probe.stats["n_absent"] == 0 and len(self_probe) == 0
+        assert self_probe.stats["n_valid"] == st0["n_valid"]
+        p0.close()
+        ks.insert_reads(d.ReadBatch.synth(eb, gcfg, 1, 0, n_reads))
+        pop = ks.popcount()
+        assert pop0 < pop < 2 * pop0
+        child = d.ReadBatch.synth(eb, gcfg, 2, 0, n_reads)
+        rb = d.KmerCounter(eb).child_only(child, ks)
+        assert [n for n, _ in eb.timings()["stages"]] == ["scan_part", "repart", "seg_probe", "seg_count"]
+        sb, cb = rb.stats, _result_checksum(rb)
+        assert cb[0] == sb["n_distinct"] == sb["n_emitted"] and cb[1] == sb["n_absent"]
+        assert 0.05 * sb["n_valid"] < sb["n_absent"] < 0.3 * sb["n_valid"]     # error k-mers of the child
+        rb.close()
+        filt = ks.to_host()
+        child.close()
+        ks.close()
+    # the direct family, an independent implementation, must give the same set and counts
+    with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=20260313, mode="direct") as ed:
+        kd = d.KmerSet(ed)
+        kd.from_host(filt)
+        del filt
+        rd = d.KmerCounter(ed).child_only(d.ReadBatch.synth(ed, gcfg, 2, 0, n_reads), kd)
+        assert [n for n, _ in ed.timings()["stages"]][0] == "probe_direct"
+        for key in ("n_windows", "n_valid", "n_absent", "n_distinct", "n_emitted"):
+            assert rd.stats[key] == sb[key], key
+        assert _result_checksum(rd) == cb
