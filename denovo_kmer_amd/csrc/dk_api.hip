@@ -253,8 +253,6 @@ dk_status dk_engine_create(const dk_config *cfg, dk_engine **out)
         return fail(nullptr, DK_ERR_INVALID_ARG, "n_hashes=%u outside 1..16", cfg->n_hashes);
     if (cfg->min_count < 1) return fail(nullptr, DK_ERR_INVALID_ARG, "min_count must be >= 1");
     if (cfg->mode > DK_MODE_BUCKETED) return fail(nullptr, DK_ERR_INVALID_ARG, "unknown mode %u", cfg->mode);
-    if (cfg->mode == DK_MODE_BUCKETED && cfg->k > 32)
-        return fail(nullptr, DK_ERR_UNSUPPORTED, "bucketed kernels handle k <= 32 (k=%u)", cfg->k);
 
     int n_dev = 0;
     hipError_t r = hipGetDeviceCount(&n_dev);
@@ -601,7 +599,6 @@ dk_status dk_set_clear(dk_set *s)
 
 static bool use_bucketed(const dk_engine *e, const dk_reads *r)
 {
-    if (e->cfg.k > 32) return false;
     if (e->cfg.mode == DK_MODE_DIRECT) return false;
     if (e->cfg.mode == DK_MODE_BUCKETED) return true;
     return dk::bucketed_pays(e, r->n_bases);
@@ -785,8 +782,10 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
             if (st == DK_ERR_OVERFLOW) {
                 // exactness first: drop the partial result and redo the batch with the direct family
                 pool_free(e, res->d_lo);
+                pool_free(e, res->d_hi);
                 pool_free(e, res->d_cnt);
                 res->d_lo = nullptr;
+                res->d_hi = nullptr;
                 res->d_cnt = nullptr;
                 res->n = 0;
                 res->n_regions = 1;
@@ -854,29 +853,34 @@ dk_status dk_result_device_view(const dk_result *cres, const void **d_kmers_lo, 
     if (res->n_regions > 1 && res->n) {
         // first device view of a regioned result: compact it into dense arrays (device-to-device)
         DK_HIP(e, hipSetDevice(e->device));
-        uint64_t *lo = nullptr;
+        uint64_t *lo = nullptr, *hi = nullptr;
         uint32_t *cnt = nullptr;
-        DK_TRY(pool_alloc(e, res->n * 8, (void **)&lo));
-        dk_status st = pool_alloc(e, res->n * 4, (void **)&cnt);
-        if (st != DK_OK) { pool_free(e, lo); return st; }
+        dk_status st = pool_alloc(e, res->n * 8, (void **)&lo);
+        if (st == DK_OK && res->wide) st = pool_alloc(e, res->n * 8, (void **)&hi);
+        if (st == DK_OK) st = pool_alloc(e, res->n * 4, (void **)&cnt);
+        if (st != DK_OK) { pool_free(e, lo); pool_free(e, hi); pool_free(e, cnt); return st; }
         uint64_t done = 0;
         hipError_t h = hipSuccess;
         for (uint32_t r = 0; r < res->n_regions && h == hipSuccess; r++) {
             const uint64_t c = res->region_n[r], src = (uint64_t)r * res->region_cap;
             if (!c) continue;
             h = hipMemcpyAsync(lo + done, res->d_lo + src, c * 8, hipMemcpyDeviceToDevice, e->stream);
+            if (h == hipSuccess && res->wide) h = hipMemcpyAsync(hi + done, res->d_hi + src, c * 8, hipMemcpyDeviceToDevice, e->stream);
             if (h == hipSuccess) h = hipMemcpyAsync(cnt + done, res->d_cnt + src, c * 4, hipMemcpyDeviceToDevice, e->stream);
             done += c;
         }
         if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
         if (h != hipSuccess) {
             pool_free(e, lo);
+            pool_free(e, hi);
             pool_free(e, cnt);
             return fail(e, DK_ERR_HIP, "compacting result regions failed: %s", hipGetErrorString(h));
         }
         pool_free(e, res->d_lo);
+        pool_free(e, res->d_hi);
         pool_free(e, res->d_cnt);
         res->d_lo = lo;
+        res->d_hi = hi;
         res->d_cnt = cnt;
         res->n_regions = 1;
         res->region_cap = res->n;

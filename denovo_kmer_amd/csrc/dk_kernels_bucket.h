@@ -107,17 +107,37 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
 // handled exactly afterwards: OR-ed into the filter one by one (insert), or probed one by one and
 // handed to seg_count as an extra per-segment list (probe).  Only if this list overflows too is the
 // batch redone by the direct family.
+// Bucket records.  k <= 32: the hash alone (a bijection of the k-mer).  33 <= k <= 64: the hash of
+// the low word tweaked by the high word, plus the high word: (h, hi) -> lo = unfmix64(h) ^ tweak(hi).
+struct Rec1 {
+    uint64_t h;
+};
+struct alignas(16) Rec2 {
+    uint64_t h, hi;
+};
+template <bool WIDE> struct RecOf { using type = Rec1; };
+template <> struct RecOf<true> { using type = Rec2; };
+
+__device__ __forceinline__ uint64_t rec_hi(const Rec1 &) { return 0; }
+__device__ __forceinline__ uint64_t rec_hi(const Rec2 &r) { return r.hi; }
+__device__ __forceinline__ uint64_t rec_lo(const Rec1 &r, uint64_t seed) { return unfmix64(r.h) ^ seed; }
+__device__ __forceinline__ uint64_t rec_lo(const Rec2 &r, uint64_t seed) { return unfmix64(r.h) ^ hash_tweak<true>(r.hi, seed); }
+__device__ __forceinline__ bool rec_eq(const Rec1 &a, const Rec1 &b) { return a.h == b.h; }
+__device__ __forceinline__ bool rec_eq(const Rec2 &a, const Rec2 &b) { return a.h == b.h && a.hi == b.hi; }
+
+template <class R>
 struct OvfList {
-    uint64_t *recs;
+    R *recs;
     unsigned long long *count;     // &Counters::n_ovf
     uint64_t cap;
 };
 
-__device__ __forceinline__ void ovf_append(const OvfList &ovf, bool pred, uint64_t h, uint32_t &n_dropped)
+template <class R>
+__device__ __forceinline__ void ovf_append(const OvfList<R> &ovf, bool pred, const R &rec, uint32_t &n_dropped)
 {
     const uint64_t slot = wave_append(pred, ovf.count);
     if (pred) {
-        if (slot < ovf.cap) ovf.recs[slot] = h;
+        if (slot < ovf.cap) ovf.recs[slot] = rec;
         else n_dropped++;
     }
 }
@@ -129,9 +149,9 @@ __device__ __forceinline__ void ovf_append(const OvfList &ovf, bool pred, uint64
 // out as per-bin runs.  Three barriers per tile (A: counts done - by the caller, B: offsets ready,
 // C: stage ready); the next tile's count phase needs no barrier because it touches only cnt[],
 // which wave 0 re-zeroes before B.
-template <int THREADS, int PER_THREAD>
+template <int THREADS, int PER_THREAD, class R>
 struct SplitLds {
-    uint64_t stage[THREADS * PER_THREAD];
+    R stage[THREADS * PER_THREAD];
     uint32_t cnt[MAX_BINS];     // per-tile counts; zero on entry to every count phase
     uint32_t off[MAX_BINS];     // tile offset of each bin in stage[]
     uint32_t delta[MAX_BINS];   // index in the piece = stage index + delta[bin]  (mod 2^32)
@@ -140,8 +160,8 @@ struct SplitLds {
 };
 
 
-template <int THREADS, int PER_THREAD>
-__device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD> &L, int nbins)
+template <int THREADS, int PER_THREAD, class R>
+__device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD, R> &L, int nbins)
 {
     for (int i = (int)threadIdx.x; i < MAX_BINS; i += THREADS) { L.cnt[i] = 0; L.cur[i] = 0; }
     __syncthreads();
@@ -149,11 +169,11 @@ __device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD> &L
 
 // out index of record idx of bin: (bin_base + bin) * bin_stride + piece_off + idx.
 // `valid` has bit j set when hs[j] holds a record (already counted into L.cnt by the caller).
-template <int THREADS, int PER_THREAD, class BinOf>
-__device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &L, const uint64_t (&hs)[PER_THREAD],
+template <int THREADS, int PER_THREAD, class R, class BinOf>
+__device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD, R> &L, const R (&hs)[PER_THREAD],
                                                  const uint32_t (&rk)[PER_THREAD], uint32_t valid, int nbins, BinOf bin_of,
                                                  uint64_t bin_base, uint64_t bin_stride, uint64_t piece_off,
-                                                 uint32_t cap, uint64_t *__restrict__ out, const OvfList &ovf,
+                                                 uint32_t cap, R *__restrict__ out, const OvfList<R> &ovf,
                                                  uint32_t &n_records, uint32_t &n_overflow, Stamps &st)
 {
     const int tid = (int)threadIdx.x;
@@ -187,25 +207,25 @@ __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD> &
     // rk[j] = rank of the record inside its bin for this tile (from the counting atomic)
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++)
-        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j])] + rk[j]] = hs[j];
+        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j].h)] + rk[j]] = hs[j];
     lds_barrier();                                       // C
     st.mark(2);
     const uint32_t total = L.total;
 #pragma unroll 8
     for (uint32_t i = tid; i < total; i += THREADS) {
-        const uint64_t h = L.stage[i];
-        const uint32_t bin = bin_of(h);
+        const R rec = L.stage[i];
+        const uint32_t bin = bin_of(rec.h);
         const uint32_t idx = i + L.delta[bin];
-        if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = h;
-        ovf_append(ovf, idx >= cap, h, n_overflow);
+        if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = rec;
+        ovf_append(ovf, idx >= cap, rec, n_overflow);
     }
     if (tid == 0) n_records += total;
     st.mark(3);
 }
 
 // piece sizes, once per workgroup: cnt_out[(bin_base + bin) * n_pieces + piece] = min(fill, cap)
-template <int THREADS, int PER_THREAD>
-__device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD> &L, int nbins, uint64_t bin_base,
+template <int THREADS, int PER_THREAD, class R>
+__device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD, R> &L, int nbins, uint64_t bin_base,
                                                   uint32_t n_pieces, uint32_t piece, uint32_t cap,
                                                   uint32_t *__restrict__ cnt_out)
 {
@@ -217,17 +237,19 @@ __device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD> 
 }
 
 // ---- level 1: packed stream -> records partitioned by the top b1 bits of the hash ---------------
-// Thread t of a tile owns PER_THREAD consecutive positions: two bases words and two mask words
-// (prefetched from HBM one tile ahead, straight to registers) cover all its windows, which are
-// produced by shifting one 128-bit register pair; the reverse complement rolls.
-template <int THREADS, int PER_THREAD, int MIN_WAVES>
+// Thread t of a tile owns PER_THREAD consecutive positions: two (k > 32: three) bases words and two
+// mask words, prefetched from HBM one tile ahead straight to registers, cover all its windows, which
+// are produced by shifting one register group; the reverse complement rolls.
+template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
-                 uint64_t *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles, OvfList ovf, Counters *ctr)
+                 typename RecOf<WIDE>::type *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles,
+                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr)
 {
+    using R = typename RecOf<WIDE>::type;
     constexpr int TILE = THREADS * PER_THREAD;
-    static_assert(PER_THREAD % 8 == 0 && PER_THREAD <= 16, "a thread's positions must stay inside two bases words");
-    __shared__ SplitLds<THREADS, PER_THREAD> L;
+    static_assert(PER_THREAD % 8 == 0 && PER_THREAD <= (WIDE ? 8 : 16), "a thread's positions must stay inside its bases words");
+    __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
     const int nbins = 1 << b1;
     const int shift = 64 - b1;
@@ -237,53 +259,80 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     Stamps st;
 
     const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
-    auto load_words = [&](uint32_t tile, uint64_t &w0, uint64_t &w1, uint64_t &m0, uint64_t &m1) {
+    auto load_words = [&](uint32_t tile, uint64_t &w0, uint64_t &w1, uint64_t &w2, uint64_t &m0, uint64_t &m1) {
         const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
         const uint64_t bw = p0 >> 5, mw = p0 >> 6;
         w0 = s.bases[bw < last_b ? bw : last_b];
         w1 = s.bases[bw + 1 < last_b ? bw + 1 : last_b];
+        w2 = WIDE ? s.bases[bw + 2 < last_b ? bw + 2 : last_b] : 0;
         m0 = s.mask[mw < last_m ? mw : last_m];
         m1 = s.mask[mw + 1 < last_m ? mw + 1 : last_m];
     };
-    const int sk = 64 - 2 * k;
+    const int sk = (WIDE ? 128 : 64) - 2 * k;            // right-alignment shift of a window
     const uint64_t kmask_shift = 64 - k;
     const uint64_t G = gridDim.x, w = blockIdx.x;
-    uint64_t nw0 = 0, nw1 = 0, nm0 = 0, nm1 = 0;
-    if (blockIdx.x < n_tiles) load_words(blockIdx.x, nw0, nw1, nm0, nm1);
+    uint64_t nw0 = 0, nw1 = 0, nw2 = 0, nm0 = 0, nm1 = 0;
+    if (blockIdx.x < n_tiles) load_words(blockIdx.x, nw0, nw1, nw2, nm0, nm1);
 
 #pragma unroll 1
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t w0 = nw0, w1 = nw1, m0 = nm0, m1 = nm1;
-        if (tile + gridDim.x < n_tiles) load_words(tile + gridDim.x, nw0, nw1, nm0, nm1);
+        const uint64_t w0 = nw0, w1 = nw1, w2 = nw2, m0 = nm0, m1 = nm1;
+        if (tile + gridDim.x < n_tiles) load_words(tile + gridDim.x, nw0, nw1, nw2, nm0, nm1);
         const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
-        // left-align the stream at p0: 64 bases in (vh, vl), 64 flags in mv
+        // left-align the stream at p0: bases in (v0, v1[, v2]), flags in (mh, ml)
         const int o = 2 * (int)(p0 & 31);                 // PER_THREAD 8: 0,16,32,48; 16: 0,32
-        const uint64_t vh = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
-        const uint64_t vl = o ? (w1 << o) : w1;
+        const uint64_t v0 = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
+        const uint64_t v1 = o ? (w1 << o) | (WIDE ? w2 >> (64 - o) : 0) : w1;
+        const uint64_t v2 = WIDE ? (o ? w2 << o : w2) : 0;
         const int ms = (int)(p0 & 63);
-        const uint64_t mv = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
+        const uint64_t mh = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
+        const uint64_t ml = WIDE ? (ms ? m1 << ms : m1) : 0;
 
-        uint64_t hs[PER_THREAD];
+        R hs[PER_THREAD];
         uint32_t rk[PER_THREAD];
         uint32_t valid = 0;
-        uint64_t rc = 0;
+        uint64_t rch = 0, rcl = 0;                        // rolling reverse complement (rch unused for k <= 32)
 #pragma unroll
         for (int j = 0; j < PER_THREAD; j++) {
-            const uint64_t win = j ? (vh << (2 * j)) | (vl >> (64 - 2 * j)) : vh;
-            const uint64_t fwd = win >> sk;
-            if (j == 0) rc = (~rev_pairs64(fwd)) >> sk;
-            else rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
-            const bool bad = ((mv << j) >> kmask_shift) != 0;
-            uint64_t km = fwd;
-            if (canonical && rc < fwd) km = rc;
-            hs[j] = fmix64(km ^ seed);
+            uint64_t kh = 0, kl;
+            bool bad;
+            if (!WIDE) {
+                const uint64_t win = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+                const uint64_t fwd = win >> sk;
+                if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
+                else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
+                bad = ((mh << j) >> kmask_shift) != 0;
+                kl = (canonical && rcl < fwd) ? rcl : fwd;
+            } else {
+                const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+                const uint64_t B = j ? (v1 << (2 * j)) | (v2 >> (64 - 2 * j)) : v1;
+                const uint64_t fh = sk ? A >> sk : A;
+                const uint64_t fl = sk ? (B >> sk) | (A << (64 - sk)) : B;
+                if (j == 0) {
+                    const uint64_t th = ~rev_pairs64(fl), tl = ~rev_pairs64(fh);
+                    rch = sk ? th >> sk : th;
+                    rcl = sk ? (tl >> sk) | (th << (64 - sk)) : tl;
+                } else {
+                    rcl = (rcl >> 2) | (rch << 62);
+                    rch = (rch >> 2) | ((uint64_t)(3u - (uint32_t)(fl & 3)) << (2 * k - 2 - 64));
+                }
+                const uint64_t mx = j ? (mh << j) | (ml >> (64 - j)) : mh;
+                bad = (mx >> kmask_shift) != 0;
+                const bool use_rc = canonical && (rch < fh || (rch == fh && rcl < fl));
+                kh = use_rc ? rch : fh;
+                kl = use_rc ? rcl : fl;
+            }
+            R rec;
+            rec.h = fmix64(kl ^ hash_tweak<WIDE>(kh, seed));
+            if constexpr (WIDE) rec.hi = kh;
+            hs[j] = rec;
             rk[j] = 0;
             if (!bad && p0 + j < s.n_bases) {
                 valid |= 1u << j;
-                rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+                rk[j] = atomicAdd(&L.cnt[bin_of(rec.h)], 1u);
             }
-            // keep the windows sequential: interleaving the eight hash chains costs ~40 VGPRs and
-            // with them half the resident waves, which hide latency better than in-wave ILP does
+            // keep the windows sequential: interleaving the hash chains costs ~40 VGPRs and with
+            // them half the resident waves, which hide latency better than in-wave ILP does
             __builtin_amdgcn_sched_barrier(0);
         }
         lds_barrier();                                   // A
@@ -301,14 +350,14 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
 // hot (every resident workgroup appends to the same 2^b2 segments of one coarse bin at a time),
 // which measured faster than private level-2 pieces; the cursor atomics are issued before the
 // scatter phase and only waited for after it, so their latency is covered.
-template <int THREADS, int PER_THREAD, int MIN_WAVES>
+template <int THREADS, int PER_THREAD, int MIN_WAVES, class R>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
-repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
-              uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, uint64_t *__restrict__ out,
-              uint32_t *__restrict__ cursor2, OvfList ovf, Counters *ctr)
+repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
+              uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
+              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr)
 {
     constexpr int TILE = THREADS * PER_THREAD;
-    __shared__ SplitLds<THREADS, PER_THREAD> L;
+    __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
     const uint32_t b = blockIdx.y;
     const uint32_t w = blockIdx.x / tiles_per_piece, t0 = (blockIdx.x % tiles_per_piece) * TILE;
@@ -320,12 +369,12 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
     for (int i = tid; i < MAX_BINS; i += THREADS) L.cnt[i] = 0;
-    const uint64_t *src = in + piece * capw;
-    uint64_t hs[PER_THREAD];
+    const R *src = in + piece * capw;
+    R hs[PER_THREAD];
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++) {
         const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
-        hs[j] = i < n ? src[i] : 0;
+        hs[j] = src[i < n ? i : 0];
     }
     __syncthreads();
     uint32_t valid = 0;
@@ -336,7 +385,7 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
         rk[j] = 0;
         if (i < n) {
             valid |= 1u << j;
-            rk[j] = atomicAdd(&L.cnt[bin_of(hs[j])], 1u);
+            rk[j] = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
         }
     }
     lds_barrier();                                       // A
@@ -363,7 +412,7 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
     lds_barrier();                                       // B
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++)
-        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j])] + rk[j]] = hs[j];
+        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j].h)] + rk[j]] = hs[j];
     if (tid < nbins) L.delta[tid] = g - ex;
     lds_barrier();                                       // C
     const uint32_t total = L.total;
@@ -371,11 +420,11 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
     uint32_t n_overflow = 0;
 #pragma unroll 4
     for (uint32_t i = tid; i < total; i += THREADS) {
-        const uint64_t h = L.stage[i];
-        const uint32_t bin = bin_of(h);
+        const R rec = L.stage[i];
+        const uint32_t bin = bin_of(rec.h);
         const uint32_t idx = i + L.delta[bin];
-        if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = h;
-        ovf_append(ovf, idx >= cap2, h, n_overflow);
+        if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = rec;
+        ovf_append(ovf, idx >= cap2, rec, n_overflow);
     }
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
@@ -384,25 +433,27 @@ repart_kernel(const uint64_t *__restrict__ in, const uint32_t *__restrict__ cnt1
 // ---- per-segment kernels ----------------------------------------------------------------------------
 // A segment's records are the concatenation of n_pieces pieces:
 //   piece r of segment s = recs[(s * n_pieces + r) * piece_cap ...], cnt[s * n_pieces + r] records
+template <class R>
 struct PieceList {
-    const uint64_t *recs;
+    const R *recs;
     const uint32_t *cnt;
     uint32_t n_pieces;     // <= MAX_R
     uint32_t piece_cap;
     // optional extra records per segment (overflow records that were absent), CSR over segments:
     // segment s owns extra[extra_off[s] .. extra_off[s + 1])
-    const uint64_t *extra;
+    const R *extra;
     const uint32_t *extra_off;
 };
 
+template <class R>
 struct SegPieces {
     uint32_t start[MAX_R + 1];     // prefix sums of the piece sizes; start[MAX_R] = records in the pieces
-    const uint64_t *base;          // first piece of the segment
+    const R *base;                 // first piece of the segment
     uint32_t piece_cap;
-    const uint64_t *extra;         // extra records of the segment (or nullptr)
+    const R *extra;                // extra records of the segment (or nullptr)
     uint32_t n_extra;
     __device__ __forceinline__ uint32_t total() const { return start[MAX_R] + n_extra; }
-    __device__ __forceinline__ uint64_t at(uint32_t i) const
+    __device__ __forceinline__ R at(uint32_t i) const
     {
         if (i >= start[MAX_R]) return extra[i - start[MAX_R]];
         uint32_t r = 0, st = 0;
@@ -413,9 +464,10 @@ struct SegPieces {
     }
 };
 
-__device__ __forceinline__ SegPieces seg_pieces(const PieceList &pl, uint64_t seg_id)
+template <class R>
+__device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint64_t seg_id)
 {
-    SegPieces sp;
+    SegPieces<R> sp;
     sp.base = pl.recs + seg_id * pl.n_pieces * (uint64_t)pl.piece_cap;
     sp.piece_cap = pl.piece_cap;
     uint32_t acc = 0;
@@ -445,12 +497,13 @@ __device__ __forceinline__ void load_segment(uint32_t *seg, const unsigned long 
     for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += (int)blockDim.x) dst[i] = src[i];
 }
 
+template <class R>
 __global__ void __launch_bounds__(SEG_THREADS)
-seg_insert_kernel(unsigned long long *filter, PieceList pl, int n_hashes, int blk_shift)
+seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
     const uint64_t seg_id = blockIdx.x;
-    const SegPieces sp = seg_pieces(pl, seg_id);
+    const SegPieces<R> sp = seg_pieces(pl, seg_id);
     const uint32_t n = sp.total();
     if (n == 0) return;                       // nothing to add: leave the segment untouched
     load_segment(seg, filter, seg_id);
@@ -463,7 +516,7 @@ seg_insert_kernel(unsigned long long *filter, PieceList pl, int n_hashes, int bl
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
-            h[u] = have[u] ? sp.at(i) : 0;
+            h[u] = sp.at(have[u] ? i : 0).h;
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
@@ -483,14 +536,15 @@ seg_insert_kernel(unsigned long long *filter, PieceList pl, int n_hashes, int bl
 }
 
 // absent records of segment s are written to miss[s * miss_cap ...], their number to miss_cnt[s]
+template <class R>
 __global__ void __launch_bounds__(SEG_THREADS)
-seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, int n_hashes, int blk_shift,
-                 uint64_t *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
+seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
+                 R *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
     __shared__ uint32_t n_miss;
     const uint64_t seg_id = blockIdx.x;
-    const SegPieces sp = seg_pieces(pl, seg_id);
+    const SegPieces<R> sp = seg_pieces(pl, seg_id);
     const uint32_t n = sp.total();
     if (n == 0) {
         if (threadIdx.x == 0) miss_cnt[seg_id] = 0;
@@ -499,21 +553,22 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, in
     if (threadIdx.x == 0) n_miss = 0;
     load_segment(seg, filter, seg_id);
     __syncthreads();
-    uint64_t *dst = miss + seg_id * miss_cap;
+    R *dst = miss + seg_id * miss_cap;
     constexpr int UNROLL = 4;                 // records in flight per thread: loads first, then the LDS tests
     for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
-        uint64_t h[UNROLL];
+        R rec[UNROLL];
         bool have[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
-            h[u] = have[u] ? sp.at(i) : 0;
+            rec[u] = sp.at(have[u] ? i : 0);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const uint32_t blk = (uint32_t)(h[u] >> blk_shift) & (SEG_BLOCKS - 1);
-            const uint32_t a = (uint32_t)(h[u] & 511), d = (uint32_t)((h[u] >> 9) & 511) | 1u;
+            const uint64_t hu = rec[u].h;
+            const uint32_t blk = (uint32_t)(hu >> blk_shift) & (SEG_BLOCKS - 1);
+            const uint32_t a = (uint32_t)(hu & 511), d = (uint32_t)((hu >> 9) & 511) | 1u;
             bool all = true;
             for (int j = 0; j < n_hashes; j++) {
                 const uint32_t bit = (a + (uint32_t)j * d) & 511;
@@ -526,7 +581,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, in
                 uint32_t wbase = 0;
                 if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
                 wbase = __shfl(wbase, leader);
-                if (absent) dst[wbase + popc_below(b)] = h[u];
+                if (absent) dst[wbase + popc_below(b)] = rec[u];
             }
         }
     }
@@ -545,20 +600,26 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList pl, in
 // input: all copies of a k-mer share a bit, so all of them are flagged.
 // Two geometries: <512 threads, 2048 slots, 64-Kbit bitmaps> for segments with thousands of absent
 // records, <128, 512, 8 Kbit> (8 KB of LDS, many workgroups per CU) when a segment holds a few hundred.
-constexpr int CNT_RPT = 16;                            // records held per thread
-
-template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS>
+template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE>
 __global__ void __launch_bounds__(CNT_THREADS)
-seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count, uint64_t region_cap,
-                 uint64_t *__restrict__ out_kmer, uint32_t *__restrict__ out_cnt, Counters *ctr)
+seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
+                 uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
+                 uint32_t *__restrict__ out_cnt, Counters *ctr)
 {
+    using R = typename RecOf<WIDE>::type;
+    constexpr int CNT_RPT = WIDE ? 8 : 16;                 // records held per thread
+    constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
+    // k <= 32: the table key is the record's hash (EMPTY = a value outside this segment's prefix).
+    // k > 32: the key is a 64-bit fingerprint of (h, hi) (EMPTY = 0); the slot's owner stores (h, hi)
+    // beside it and every record re-checks the full key after the insert phase, so a fingerprint
+    // collision is detected (and the batch redone exactly) instead of merging two k-mers.
     __shared__ unsigned long long keys[CNT_SLOTS];
+    __shared__ unsigned long long key_h[WIDE ? CNT_SLOTS : 1], key_hi[WIDE ? CNT_SLOTS : 1];
     __shared__ uint32_t cnts[CNT_SLOTS];
     __shared__ uint32_t bm_a[CNT_BM_WORDS], bm_b[CNT_BM_WORDS];
     __shared__ uint32_t wave_sums[CNT_THREADS / 64];
     __shared__ uint32_t total;
     __shared__ unsigned long long gbase;
-    constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6;
     uint32_t n_distinct = 0, n_fail = 0;
@@ -566,22 +627,29 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
     const uint32_t region = blockIdx.x % RESULT_REGIONS;
     unsigned long long *fill = &ctr->region_fill[region];
     const uint64_t region_base = (uint64_t)region * region_cap;
+    auto fp_of = [](const R &rec) -> unsigned long long {
+        if constexpr (WIDE) {
+            const unsigned long long f = fmix64(rec.h ^ (rec_hi(rec) * 0x9E3779B97F4A7C15ULL));
+            return f ? f : 1ULL;
+        } else {
+            return rec.h;
+        }
+    };
     // persistent: a workgroup walks segments blockIdx.x, +gridDim.x, ... (launching one tiny
     // workgroup per segment cost ~50 ns of wall time each at 2^18 segments)
     for (uint64_t seg_id = blockIdx.x; seg_id < n_seg; seg_id += gridDim.x) {
-        const SegPieces sp = seg_pieces(pl, seg_id);
+        const SegPieces<R> sp = seg_pieces(pl, seg_id);
         const uint32_t n = sp.total();
         if (n == 0) continue;
-        // a value no record of this segment can take: its top T bits differ from the segment id
-        const unsigned long long EMPTY = (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
+        const unsigned long long EMPTY = WIDE ? 0ULL : (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
         const uint32_t n_chunks = (n + CNT_CHUNK - 1) / CNT_CHUNK;
         const bool single = n_chunks == 1;                 // the common case: the records stay in registers
-        uint64_t hv[CNT_RPT];
+        R hv[CNT_RPT];
         auto load_chunk = [&](uint32_t c) {
 #pragma unroll
             for (int u = 0; u < CNT_RPT; u++) {
                 const uint32_t i = c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid;
-                hv[u] = i < n ? sp.at(i) : 0;
+                hv[u] = sp.at(i < n ? i : 0);
             }
         };
         auto have = [&](uint32_t c, int u) -> bool { return c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid < n; };
@@ -589,8 +657,8 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
         uint32_t bm_words = 64;
         while (bm_words * 4 < n && bm_words < (uint32_t)CNT_BM_WORDS) bm_words <<= 1;
         const uint32_t bm_mask = bm_words * 32 - 1;
-        auto bit_of = [=](uint64_t h, uint32_t &w, uint32_t &m) {
-            const uint32_t b = (uint32_t)(h >> 20) & bm_mask;
+        auto bit_of = [=](const R &rec, uint32_t &w, uint32_t &m) {
+            const uint32_t b = (uint32_t)(fp_of(rec) >> 20) & bm_mask;
             w = b >> 5;
             m = 1u << (b & 31);
         };
@@ -656,7 +724,8 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
                     if (uniq) {
                         const uint64_t pos = o + (uint64_t)popc_below(bal);
                         if (pos < region_cap) {
-                            out_kmer[region_base + pos] = unfmix64(hv[u]) ^ seed;
+                            out_kmer[region_base + pos] = rec_lo(hv[u], seed);
+                            if constexpr (WIDE) out_hi[region_base + pos] = rec_hi(hv[u]);
                             out_cnt[region_base + pos] = 1;
                         } else {
                             n_fail++;               // region full: host redoes the batch with the direct family
@@ -681,28 +750,41 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
                 for (uint32_t i = tid; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
                 if (tid == 0) total = 0;                       // doubles as the "round does not fit" flag
                 __syncthreads();
-                for (uint32_t c = 0; c < n_chunks; c++) {
-                    if (!single) load_chunk(c);
+                for (int phase = 0; phase < (WIDE ? 2 : 1); phase++) {
+                    // phase 0: insert and count.  phase 1 (k > 32): re-check the full key of every record
+                    for (uint32_t c = 0; c < n_chunks; c++) {
+                        if (!single) load_chunk(c);
 #pragma unroll
-                    for (int u = 0; u < CNT_RPT; u++) {
-                        if (!have(c, u)) continue;
-                        const uint64_t h = hv[u];
-                        uint32_t w, m;
-                        bit_of(h, w, m);
-                        if (!(bm_b[w] & m)) continue;
-                        const uint32_t rr = (uint32_t)((((h >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20);
-                        if (rr != r) continue;
-                        uint32_t slot = (uint32_t)(h >> 8) & slot_mask;
-                        uint32_t tries = 0;
-                        for (; tries < 64; tries++) {
-                            const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, (unsigned long long)h);
-                            if (prev == EMPTY || prev == h) { atomicAdd(&cnts[slot], 1u); break; }
-                            slot = (slot + 1) & slot_mask;
+                        for (int u = 0; u < CNT_RPT; u++) {
+                            if (!have(c, u)) continue;
+                            const R rec = hv[u];
+                            uint32_t w, m;
+                            bit_of(rec, w, m);
+                            if (!(bm_b[w] & m)) continue;
+                            const unsigned long long f = fp_of(rec);
+                            const uint32_t rr = (uint32_t)((((f >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20);
+                            if (rr != r) continue;
+                            uint32_t slot = (uint32_t)(f >> 8) & slot_mask;
+                            uint32_t tries = 0;
+                            if (phase == 0) {
+                                for (; tries < 64; tries++) {
+                                    const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, f);
+                                    if (prev == EMPTY) {
+                                        if constexpr (WIDE) { key_h[slot] = rec.h; key_hi[slot] = rec_hi(rec); }
+                                    }
+                                    if (prev == EMPTY || prev == f) { atomicAdd(&cnts[slot], 1u); break; }
+                                    slot = (slot + 1) & slot_mask;
+                                }
+                                if (tries == 64) total = 1;        // too crowded: split this round
+                            } else {
+                                for (; tries < 64 && keys[slot] != f; tries++) slot = (slot + 1) & slot_mask;
+                                if (tries == 64 || key_h[slot] != rec.h || key_hi[slot] != rec_hi(rec)) n_fail++;
+                            }
                         }
-                        if (tries == 64) total = 1;            // too crowded: split this round
                     }
+                    __syncthreads();
+                    if (total) break;
                 }
-                __syncthreads();
                 if (total) {
                     if (rounds >= (1u << 18)) { n_fail++; r = rounds; break; }   // cannot split further: redo on the direct family
                     rounds *= 4;
@@ -719,7 +801,13 @@ seg_count_kernel(PieceList pl, uint64_t n_seg, int T, uint64_t seed, uint32_t mi
                 for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS) {
                     if (keys[sl] != EMPTY && cnts[sl] >= min_count) {
                         if (o < region_cap) {
-                            out_kmer[region_base + o] = unfmix64(keys[sl]) ^ seed;
+                            if constexpr (WIDE) {
+                                const Rec2 kr{key_h[sl], key_hi[sl]};
+                                out_kmer[region_base + o] = rec_lo(kr, seed);
+                                out_hi[region_base + o] = kr.hi;
+                            } else {
+                                out_kmer[region_base + o] = unfmix64(keys[sl]) ^ seed;
+                            }
                             out_cnt[region_base + o] = cnts[sl];
                         } else {
                             n_fail++;
@@ -756,21 +844,23 @@ __device__ __forceinline__ bool ovf_filter_op(unsigned long long *filter, uint64
 }
 
 // OR the overflow records into the filter (after seg_insert has written its segments back)
+template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-ovf_insert_kernel(unsigned long long *filter, OvfList ovf, int log2_blocks, int n_hashes)
+ovf_insert_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes)
 {
     unsigned long long n = *ovf.count;
     if (n > ovf.cap) n = ovf.cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        ovf_filter_op(filter, ovf.recs[i], log2_blocks, n_hashes, true);
+        ovf_filter_op(filter, ovf.recs[i].h, log2_blocks, n_hashes, true);
 }
 
 // Probe the overflow records (filter == nullptr: every record counts as absent); absent ones are
 // appended to `miss` and tallied per segment for the CSR build.
+template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-ovf_probe_kernel(unsigned long long *filter, OvfList ovf, int log2_blocks, int n_hashes, int T,
-                 uint64_t *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
+ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes, int T,
+                 R *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
 {
     unsigned long long n = *ovf.count;
     if (n > ovf.cap) n = ovf.cap;
@@ -778,12 +868,12 @@ ovf_probe_kernel(unsigned long long *filter, OvfList ovf, int log2_blocks, int n
     const uint64_t n_round = (n + 63) & ~63ULL;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool have = i < n;
-        const uint64_t h = have ? ovf.recs[i] : 0;
-        const bool absent = have && (filter ? !ovf_filter_op(filter, h, log2_blocks, n_hashes, false) : true);
+        const R rec = ovf.recs[have ? i : 0];
+        const bool absent = have && (filter ? !ovf_filter_op(filter, rec.h, log2_blocks, n_hashes, false) : true);
         const uint64_t slot = wave_append(absent, &ctr->n_ovf_miss);
         if (absent) {
-            miss[slot] = h;
-            atomicAdd(&seg_hist[h >> (64 - T)], 1u);
+            miss[slot] = rec;
+            atomicAdd(&seg_hist[rec.h >> (64 - T)], 1u);
         }
     }
 }
@@ -804,15 +894,16 @@ ovf_scan_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ off, u
 }
 
 // place the absent overflow records into their segment's slice
+template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-ovf_scatter_kernel(const uint64_t *__restrict__ miss, uint64_t n, int T, const uint32_t *__restrict__ off,
-                   uint32_t *fill, uint64_t *__restrict__ extra)
+ovf_scatter_kernel(const R *__restrict__ miss, uint64_t n, int T, const uint32_t *__restrict__ off,
+                   uint32_t *fill, R *__restrict__ extra)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t h = miss[i];
-        const uint64_t seg = h >> (64 - T);
-        extra[off[seg] + atomicAdd(&fill[seg], 1u)] = h;
+        const R rec = miss[i];
+        const uint64_t seg = rec.h >> (64 - T);
+        extra[off[seg] + atomicAdd(&fill[seg], 1u)] = rec;
     }
 }
 
@@ -837,7 +928,7 @@ inline int scan_variant()
 
 inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
 {
-    if (e->cfg.k > 32) return false;
+    const bool wide = e->cfg.k > 32;
     p->T = (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
     if (p->T < 1 || p->T > 2 * MAX_BIN_BITS) return false;
     static const int b1_up = [] { const char *v = getenv("DK_B1_UP"); return v ? atoi(v) : 0; }();
@@ -850,8 +941,9 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
     p->n_seg = 1ULL << p->T;
     p->n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
     const int v = scan_variant();
-    p->tile = v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : 1024 * 8;
-    const int blocks_per_cu = v == 1 ? 1 : v == 3 ? 4 : 2;
+    // 16-byte records (k > 32): 512 threads x 8 positions so that the LDS stage stays at 64 KiB
+    p->tile = wide ? 512 * 8 : v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : 1024 * 8;
+    const int blocks_per_cu = wide ? 2 : v == 1 ? 1 : v == 3 ? 4 : 2;
     const uint64_t n_tiles = (r->n_bases + p->tile - 1) / p->tile;
     if (n_tiles > 0xFFFFFFFFULL) return false;
     p->G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), (uint64_t)e->n_cu * blocks_per_cu);
@@ -872,21 +964,23 @@ inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases)
 {
     const uint64_t filter_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
     const int T = (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
-    if (e->cfg.k > 32 || T < 1 || T > 2 * MAX_BIN_BITS) return false;
+    if (T < 1 || T > 2 * MAX_BIN_BITS) return false;
     return filter_bytes >= (32ULL << 20) && n_bases * 16 >= filter_bytes;
 }
 
+template <class R>
 struct BucketBufs {
-    uint64_t *a = nullptr, *b = nullptr;      // level-1 pieces (later: absent lists) / segment regions
+    R *a = nullptr, *b = nullptr;             // level-1 pieces (later: absent lists) / segment regions
     uint32_t *cnt = nullptr;                  // cnt1 [p1 * G] | cursor2 [n_seg] | miss_cnt [n_seg]
     uint32_t *cnt1 = nullptr, *cursor2 = nullptr, *miss_cnt = nullptr;
-    uint64_t *ovf = nullptr;                  // overflow records
+    R *ovf = nullptr;                         // overflow records
     uint64_t ovf_cap = 0;
-    uint64_t *ovf_miss = nullptr, *extra = nullptr;   // probe: absent overflow records, then sorted by segment
+    R *ovf_miss = nullptr, *extra = nullptr;  // probe: absent overflow records, then sorted by segment
     uint32_t *extra_idx = nullptr;            // seg_hist [n_seg] | extra_off [n_seg + 1] | fill [n_seg]
 };
 
-inline void free_bufs(dk_engine *e, BucketBufs &B)
+template <class R>
+inline void free_bufs(dk_engine *e, BucketBufs<R> &B)
 {
     pool_free(e, B.a);
     pool_free(e, B.b);
@@ -899,21 +993,24 @@ inline void free_bufs(dk_engine *e, BucketBufs &B)
 
 // scan_part + repart: afterwards B.b / B.cursor2 hold every record of the batch grouped by segment,
 // except the records that did not fit, which are in B.ovf (Counters::n_ovf of them)
-inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p, BucketBufs &B)
+template <bool WIDE>
+inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p,
+                                    BucketBufs<typename RecOf<WIDE>::type> &B)
 {
+    using R = typename RecOf<WIDE>::type;
     const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
     const uint64_t lvl1_recs = (uint64_t)p.p1 * p.G * p.capw;
-    DK_TRY(pool_alloc(e, std::max(seg_recs, lvl1_recs) * 8, (void **)&B.a));
-    DK_TRY(pool_alloc(e, seg_recs * 8, (void **)&B.b));
+    DK_TRY(pool_alloc(e, std::max(seg_recs, lvl1_recs) * sizeof(R), (void **)&B.a));
+    DK_TRY(pool_alloc(e, seg_recs * sizeof(R), (void **)&B.b));
     const uint64_t n1 = (uint64_t)p.p1 * p.G;
     DK_TRY(pool_alloc(e, (n1 + 2 * p.n_seg) * 4, (void **)&B.cnt));
     B.cnt1 = B.cnt;
     B.cursor2 = B.cnt + n1;
     B.miss_cnt = B.cursor2 + p.n_seg;
     B.ovf_cap = std::max<uint64_t>(1ULL << 20, p.n_max / 8);
-    DK_TRY(pool_alloc(e, B.ovf_cap * 8, (void **)&B.ovf));
+    DK_TRY(pool_alloc(e, B.ovf_cap * sizeof(R), (void **)&B.ovf));
     DK_HIP(e, hipMemsetAsync(B.cursor2, 0, p.n_seg * 4, e->stream));
-    const OvfList ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+    const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
 
     StreamView sv;
     sv.bases = r->d_bases;
@@ -922,32 +1019,32 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     sv.n_bwords = (r->n_bases + 31) / 32;
     sv.n_mwords = (r->n_bases + 63) / 64;
     const uint32_t n_tiles = (uint32_t)((r->n_bases + p.tile - 1) / p.tile);
-#define DK_SCAN_LAUNCH(TH, PT, W)                                                                                  \
-    scan_part_kernel<TH, PT, W><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
-                                                           p.b1, p.capw, B.a, B.cnt1, n_tiles, ovf, e->d_ctr)
-    switch (scan_variant()) {
-    case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
-    case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
-    case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
-    default: DK_SCAN_LAUNCH(1024, 8, 8); break;
-    }
-#undef DK_SCAN_LAUNCH
-    DK_HIP(e, hipGetLastError());
-    stage_mark(e, "scan_part");
+#define DK_SCAN_LAUNCH(TH, PT, W)                                                                                        \
+    scan_part_kernel<TH, PT, W, WIDE><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
+                                                                 p.b1, p.capw, B.a, B.cnt1, n_tiles, ovf, e->d_ctr)
 #define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
     do {                                                                                                  \
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
-        repart_kernel<TH, PT, W><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                             \
+        repart_kernel<TH, PT, W, R><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                          \
             B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, ovf, e->d_ctr);             \
     } while (0)
-    static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
-    switch (rv) {
-    case 1: DK_REPART_LAUNCH(512, 8, 8); break;
-    case 2: DK_REPART_LAUNCH(512, 16, 4); break;
-    case 3: DK_REPART_LAUNCH(256, 16, 4); break;
-    case 4: DK_REPART_LAUNCH(256, 8, 8); break;
-    default: DK_REPART_LAUNCH(1024, 8, 8); break;
+    if constexpr (WIDE) {
+        DK_SCAN_LAUNCH(512, 8, 4);
+        DK_HIP(e, hipGetLastError());
+        stage_mark(e, "scan_part");
+        DK_REPART_LAUNCH(512, 8, 8);
+    } else {
+        switch (scan_variant()) {
+        case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
+        case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
+        case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
+        default: DK_SCAN_LAUNCH(1024, 8, 8); break;
+        }
+        DK_HIP(e, hipGetLastError());
+        stage_mark(e, "scan_part");
+        DK_REPART_LAUNCH(1024, 8, 8);
     }
+#undef DK_SCAN_LAUNCH
 #undef DK_REPART_LAUNCH
     DK_HIP(e, hipGetLastError());
     stage_mark(e, "repart");
@@ -966,22 +1063,24 @@ inline dk_status sync_counters(dk_engine *e, const char *what)
 
 // Returns DK_ERR_OVERFLOW when even the overflow list overflowed: the caller then runs the direct
 // family on the whole batch, which is exact (OR is idempotent, records already inserted do no harm).
-inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
+template <bool WIDE>
+inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
 {
+    using R = typename RecOf<WIDE>::type;
     BucketPlan p;
     if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
-    BucketBufs B;
-    dk_status st = bucketed_partition(e, r, p, B);
+    BucketBufs<R> B;
+    dk_status st = bucketed_partition<WIDE>(e, r, p, B);
     if (st == DK_OK) {
-        const PieceList pl{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
-        seg_insert_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+        const PieceList<R> pl{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
+        seg_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
             s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
         hipError_t h = hipGetLastError();
         if (h == hipSuccess) {
             stage_mark(e, "seg_insert");
             // overflow records (normally none): the kernel reads their number from device memory
-            const OvfList ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
-            ovf_insert_kernel<<<e->n_cu * 2, DIRECT_BLOCK, 0, e->stream>>>(
+            const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+            ovf_insert_kernel<R><<<e->n_cu * 2, DIRECT_BLOCK, 0, e->stream>>>(
                 s->d_words, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes);
             h = hipGetLastError();
         }
@@ -993,21 +1092,23 @@ inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
     return st;
 }
 
-inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result *res)
+template <bool WIDE>
+inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk_result *res)
 {
+    using R = typename RecOf<WIDE>::type;
     BucketPlan p;
     if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
-    BucketBufs B;
-    dk_status st = bucketed_partition(e, r, p, B);
-    PieceList list{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
+    BucketBufs<R> B;
+    dk_status st = bucketed_partition<WIDE>(e, r, p, B);
+    PieceList<R> list{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
-        seg_probe_kernel<<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+        seg_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
             s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
         else stage_mark(e, "seg_probe");
-        list = PieceList{B.a, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
+        list = PieceList<R>{B.a, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
     }
     if (st == DK_OK) st = sync_counters(e, "bucketed probe");
     uint64_t n_absent = 0;
@@ -1019,16 +1120,16 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
     // and hand them to seg_count as an extra list of their segment
     if (st == DK_OK && e->h_ctr->n_ovf) {
         const uint64_t n_ovf = e->h_ctr->n_ovf;
-        st = pool_alloc(e, n_ovf * 8, (void **)&B.ovf_miss);
-        if (st == DK_OK) st = pool_alloc(e, n_ovf * 8, (void **)&B.extra);
+        st = pool_alloc(e, n_ovf * sizeof(R), (void **)&B.ovf_miss);
+        if (st == DK_OK) st = pool_alloc(e, n_ovf * sizeof(R), (void **)&B.extra);
         if (st == DK_OK) st = pool_alloc(e, (3 * p.n_seg + 1) * 4, (void **)&B.extra_idx);
         hipError_t h = hipSuccess;
         if (st == DK_OK) {
             uint32_t *hist = B.extra_idx, *off = hist + p.n_seg, *fill = off + p.n_seg + 1;
-            const OvfList ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+            const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
             h = hipMemsetAsync(B.extra_idx, 0, (3 * p.n_seg + 1) * 4, e->stream);
             if (h == hipSuccess) {
-                ovf_probe_kernel<<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                ovf_probe_kernel<R><<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
                     s ? s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes, p.T,
                     B.ovf_miss, hist, e->d_ctr);
                 ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)p.n_seg);
@@ -1042,7 +1143,7 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
             }
             if (st == DK_OK && e->h_ctr->n_ovf_miss) {
                 const uint64_t n_om = e->h_ctr->n_ovf_miss;
-                ovf_scatter_kernel<<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                ovf_scatter_kernel<R><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
                     B.ovf_miss, n_om, p.T, off, fill, B.extra);
                 h = hipGetLastError();
                 if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow scatter failed: %s", hipGetErrorString(h));
@@ -1064,16 +1165,17 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
         const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, p.n_seg);
         const uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536 + e->h_ctr->n_ovf_miss;
         st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
+        if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
         if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {
             if (n_absent / p.n_seg >= 1500) {
                 const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 6);
-                seg_count_kernel<512, 2048, 2048><<<cgrid, 512, 0, e->stream>>>(
-                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_cnt, e->d_ctr);
+                seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
+                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             } else {
                 const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 32);
-                seg_count_kernel<128, 512, 256><<<cgrid, 128, 0, e->stream>>>(
-                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_cnt, e->d_ctr);
+                seg_count_kernel<128, 512, 256, WIDE><<<cgrid, 128, 0, e->stream>>>(
+                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             }
             hipError_t h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
@@ -1093,6 +1195,16 @@ inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_r
     }
     free_bufs(e, B);
     return st;
+}
+
+inline dk_status bucketed_insert(dk_engine *e, dk_set *s, const dk_reads *r)
+{
+    return e->cfg.k > 32 ? bucketed_insert_t<true>(e, s, r) : bucketed_insert_t<false>(e, s, r);
+}
+
+inline dk_status bucketed_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result *res)
+{
+    return e->cfg.k > 32 ? bucketed_probe_t<true>(e, s, r, res) : bucketed_probe_t<false>(e, s, r, res);
 }
 
 }  // namespace dk

@@ -38,7 +38,7 @@ def test_cpp_host_reports_no_device(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,mode", [(31, 1), (31, 2), (45, 1)])
+@pytest.mark.parametrize("k,mode", [(31, 1), (31, 2), (45, 1), (45, 2)])
 def test_cpp_host_matches_oracle(tmp_path, rng, k, mode):
     exe = build_cli(tmp_path)
     parents, child = related_trio(rng, genome_len=2500, n_reads=70, read_len=120)

@@ -26,9 +26,6 @@ def dk():
 
 
 def make_engine(mode="direct", **kw):
-    k = kw.get("k", 31)
-    if mode == "bucketed" and k > 32:
-        pytest.skip("bucketed kernels handle k <= 32")
     return dk().Engine(mode=mode, **kw)
 
 
@@ -328,10 +325,11 @@ def test_synthetic_trio_parity_config0_scale(mode, k, log2_bits):
         assert eng.timings()["total_ms"] > 0
 
 
-@pytest.mark.parametrize("mode,k", [("direct", 51), ("direct", 31), ("bucketed", 31), ("direct", 64)])
+@pytest.mark.parametrize("mode,k", [("direct", 51), ("bucketed", 51), ("direct", 31), ("bucketed", 31),
+                                    ("direct", 64), ("bucketed", 64), ("bucketed", 33)])
 def test_long_reads_config4_shape(mode, k):
-    # BASELINE.json configs[4] shape: ONT-style 10 kb reads with 5 % errors (k=51 runs on the direct
-    # family; the bucketed family covers k <= 32)
+    # BASELINE.json configs[4] shape: ONT-style 10 kb reads with 5 % errors, both kernel families
+    # (k > 32 uses 128-bit k-mers and 16-byte bucket records)
     d = dk()
     n_reads, L, log2_bits = 300, 10_000, 26
     ocfg = orc.synth_cfg(genome_len=400_000, read_len=L, err_rate=0.05)
