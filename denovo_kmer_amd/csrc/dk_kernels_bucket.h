@@ -1168,7 +1168,13 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
         if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {
-            if (n_absent / p.n_seg >= 1500) {
+            const uint64_t per_seg = n_absent / p.n_seg;
+            if (per_seg >= (WIDE ? 3500u : 7000u)) {
+                // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 2);
+                seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
+                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
+            } else if (per_seg >= 1500) {
                 const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 6);
                 seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
                     list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
