@@ -365,3 +365,13 @@ class KmerCounter:
     def child_only(self, batch, parents):
         """k-mers of the (child) batch absent from the parent set, with their child counts"""
         return self._probe(parents, batch)
+
+    def merge(self, tables, min_count=1):
+        """sum several KmerCounts by k-mer (batches of one sample, or shards); the inputs should come
+        from an engine with min_count=1, the threshold is applied to the summed counts here"""
+        e = self.engine
+        arr = (C.c_void_p * len(tables))(*[t._h for t in tables])
+        h = C.c_void_p()
+        st = DkStats()
+        e.check(e._lib.dk_result_merge(e.handle, arr, len(tables), min_count, C.byref(h), C.byref(st)))
+        return KmerCounts(e, h, st.as_dict())

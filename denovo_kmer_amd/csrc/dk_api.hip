@@ -215,6 +215,73 @@ static dk_status probe_direct(dk_engine *e, dk_set *s, const dk_reads *r, dk_res
     return DK_OK;
 }
 
+template <bool WIDE>
+static dk_status merge_results(dk_engine *e, const dk_result *const *results, uint32_t n_results, uint32_t min_count,
+                               dk_result *res)
+{
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_results; i++) total += results[i]->n;
+    if (total == 0) return DK_OK;
+    if (total >= 0xFFFFFFFFULL) return fail(e, DK_ERR_OVERFLOW, "more than 2^32-1 entries to merge");
+    uint64_t *lo = nullptr, *hi = nullptr;
+    uint32_t *cnt = nullptr, *slots = nullptr, *counts = nullptr;
+    auto cleanup = [&]() {
+        pool_free(e, lo);
+        pool_free(e, hi);
+        pool_free(e, cnt);
+        pool_free(e, slots);
+        pool_free(e, counts);
+    };
+    dk_status st = pool_alloc(e, total * 8, (void **)&lo);
+    if (st == DK_OK && WIDE) st = pool_alloc(e, total * 8, (void **)&hi);
+    if (st == DK_OK) st = pool_alloc(e, total * 4, (void **)&cnt);
+    const int log2_cap = std::max(10, ceil_log2(2 * total));
+    const uint64_t cap = 1ULL << log2_cap;
+    if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&slots);
+    if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&counts);
+    if (st == DK_OK) st = pool_alloc(e, total * 8, (void **)&res->d_lo);
+    if (st == DK_OK && WIDE) st = pool_alloc(e, total * 8, (void **)&res->d_hi);
+    if (st == DK_OK) st = pool_alloc(e, total * 4, (void **)&res->d_cnt);
+    if (st != DK_OK) { cleanup(); return st; }
+    // concatenate the inputs (region by region) into dense candidate arrays
+    hipError_t h = hipSuccess;
+    uint64_t done = 0;
+    for (uint32_t i = 0; i < n_results && h == hipSuccess; i++) {
+        const dk_result *r = results[i];
+        for (uint32_t g = 0; g < r->n_regions && h == hipSuccess; g++) {
+            const uint64_t c = r->region_n[g], src = (uint64_t)g * r->region_cap;
+            if (!c) continue;
+            h = hipMemcpyAsync(lo + done, r->d_lo + src, c * 8, hipMemcpyDeviceToDevice, e->stream);
+            if (h == hipSuccess && WIDE) h = hipMemcpyAsync(hi + done, r->d_hi + src, c * 8, hipMemcpyDeviceToDevice, e->stream);
+            if (h == hipSuccess) h = hipMemcpyAsync(cnt + done, r->d_cnt + src, c * 4, hipMemcpyDeviceToDevice, e->stream);
+            done += c;
+        }
+    }
+    if (h == hipSuccess) h = hipMemsetAsync(slots, 0xFF, cap * 4, e->stream);
+    if (h == hipSuccess) h = hipMemsetAsync(counts, 0, cap * 4, e->stream);
+    if (h == hipSuccess) {
+        merge_insert_kernel<WIDE><<<grid_for(e, total, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            lo, hi, cnt, total, slots, counts, log2_cap, e->cfg.seed);
+        h = hipGetLastError();
+    }
+    if (h == hipSuccess) {
+        stage_mark(e, "merge_insert");
+        count_emit_kernel<WIDE><<<grid_for(e, cap, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            lo, hi, slots, counts, cap, min_count, e->d_ctr, res->d_lo, res->d_hi, res->d_cnt);
+        h = hipGetLastError();
+    }
+    if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "merge kernels failed: %s", hipGetErrorString(h)); }
+    stage_mark(e, "merge_emit");
+    st = read_counters(e);
+    cleanup();
+    if (st != DK_OK) return st;
+    res->n = e->h_ctr->n_emitted;
+    res->n_regions = 1;
+    res->region_cap = total;
+    res->region_n[0] = res->n;
+    return DK_OK;
+}
+
 #define CHECK_ARG(e, cond)                                                              \
     do {                                                                                \
         if (!(cond)) return dk::fail((e), DK_ERR_INVALID_ARG, "invalid argument: %s", #cond); \
@@ -890,6 +957,43 @@ dk_status dk_result_device_view(const dk_result *cres, const void **d_kmers_lo, 
     if (d_kmers_hi) *d_kmers_hi = res->d_hi;
     if (d_counts) *d_counts = res->d_cnt;
     if (n) *n = res->n;
+    return DK_OK;
+}
+
+dk_status dk_result_merge(dk_engine *e, const dk_result *const *results, uint32_t n_results,
+                          uint32_t min_count, dk_result **out, dk_stats *stats)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr && (results != nullptr || n_results == 0));
+    CHECK_ARG(e, min_count >= 1);
+    *out = nullptr;
+    const bool wide = e->cfg.k > 32;
+    for (uint32_t i = 0; i < n_results; i++) CHECK_ARG(e, results[i] != nullptr && results[i]->e == e && results[i]->wide == wide);
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_result *res = new (std::nothrow) dk_result();
+    if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
+    res->e = e;
+    res->d_lo = res->d_hi = nullptr;
+    res->d_cnt = nullptr;
+    res->n = 0;
+    res->n_regions = 1;
+    res->region_cap = 0;
+    memset(res->region_n, 0, sizeof res->region_n);
+    res->wide = wide;
+    hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+    if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
+    memset(e->h_ctr, 0, sizeof(Counters));
+    stage_begin(e);
+    dk_status st = wide ? merge_results<true>(e, results, n_results, min_count, res)
+                        : merge_results<false>(e, results, n_results, min_count, res);
+    if (st == DK_OK) st = stage_end(e);
+    if (st != DK_OK) { dk_result_destroy(res); return st; }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_distinct = e->h_ctr->n_distinct;
+        stats->n_emitted = res->n;
+    }
+    *out = res;
     return DK_OK;
 }
 

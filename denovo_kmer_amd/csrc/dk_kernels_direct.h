@@ -348,6 +348,37 @@ count_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__rest
     }
 }
 
+// merge of (k-mer, count) tables: same table as count_insert, the entry's count is added
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+merge_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,
+                    const uint32_t *__restrict__ cand_cnt, uint64_t n_cand, uint32_t *slots, uint32_t *counts,
+                    int log2_cap, uint64_t seed)
+{
+    const uint64_t cap_mask = (1ULL << log2_cap) - 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += stride) {
+        Kmer km{WIDE ? cand_hi[i] : 0, cand_lo[i]};
+        uint64_t s = hash_kmer<WIDE>(km, seed) >> (64 - log2_cap);
+        for (;;) {
+            uint32_t cur = slots[s];
+            if (cur == SLOT_EMPTY) cur = atomicCAS(&slots[s], SLOT_EMPTY, (uint32_t)i);
+            if (cur == SLOT_EMPTY) break;                       // claimed
+            if (cand_lo[cur] == km.lo && (!WIDE || cand_hi[cur] == km.hi)) break;
+            s = (s + 1) & cap_mask;
+        }
+        // saturating add: a count never wraps
+        const uint32_t add = cand_cnt[i];
+        uint32_t old = counts[s];
+        for (;;) {
+            const uint32_t want = old > 0xFFFFFFFFu - add ? 0xFFFFFFFFu : old + add;
+            const uint32_t seen = atomicCAS(&counts[s], old, want);
+            if (seen == old) break;
+            old = seen;
+        }
+    }
+}
+
 template <bool WIDE>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 count_emit_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,

@@ -156,6 +156,11 @@ dk_status dk_result_size(const dk_result *res, uint64_t *n);
 dk_status dk_result_copy(const dk_result *res, uint64_t *kmers_lo, uint64_t *kmers_hi, uint32_t *counts);
 dk_status dk_result_device_view(const dk_result *res, const void **d_kmers_lo, const void **d_kmers_hi,
                                 const void **d_counts, uint64_t *n);
+/* Sum n_results tables by k-mer (a child processed in several batches, or the per-GPU tables of a
+ * sharded run) and keep the k-mers with a summed count >= min_count.  The inputs should have been
+ * produced with min_count = 1, otherwise k-mers below the threshold in every batch are already gone. */
+dk_status dk_result_merge(dk_engine *e, const dk_result *const *results, uint32_t n_results,
+                          uint32_t min_count, dk_result **out, dk_stats *stats);
 void      dk_result_destroy(dk_result *res);
 
 #ifdef __cplusplus

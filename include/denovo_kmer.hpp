@@ -151,6 +151,20 @@ public:
     explicit KmerCounter(Engine &e) : e_(e) {}
     KmerCounts count(const ReadBatch &b) { return run(nullptr, b); }
     KmerCounts child_only(const ReadBatch &child, const KmerSet &parents) { return run(parents.get(), child); }
+    // device-resident tables for multi-batch samples: probe each batch, merge the handles, fetch once
+    dk_result *child_only_device(const ReadBatch &child, const KmerSet &parents)
+    {
+        dk_result *res = nullptr;
+        check(dk_probe(e_.get(), parents.get(), child.get(), &res, nullptr), e_.get());
+        return res;
+    }
+    KmerCounts merge(const std::vector<dk_result *> &tables, uint32_t min_count)
+    {
+        KmerCounts out;
+        dk_result *res = nullptr;
+        check(dk_result_merge(e_.get(), tables.data(), (uint32_t)tables.size(), min_count, &res, &out.stats), e_.get());
+        return fetch(res, out);
+    }
 
 private:
     KmerCounts run(dk_set *s, const ReadBatch &b)
@@ -158,6 +172,10 @@ private:
         KmerCounts out;
         dk_result *res = nullptr;
         check(dk_probe(e_.get(), s, b.get(), &res, &out.stats), e_.get());
+        return fetch(res, out);
+    }
+    KmerCounts fetch(dk_result *res, KmerCounts &out)
+    {
         uint64_t n = 0;
         dk_status st = dk_result_size(res, &n);
         if (st == DK_OK) {

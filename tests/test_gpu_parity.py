@@ -536,3 +536,33 @@ def test_full_size_configs1_properties():
         for key in ("n_windows", "n_valid", "n_absent", "n_distinct", "n_emitted"):
             assert rd.stats[key] == sb[key], key
         assert _result_checksum(rd) == cb
+
+
+# ---- multi-batch samples: device-side merge of per-batch tables ----------------------------------------
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k", [31, 45])
+def test_result_merge_equals_whole_sample(rng, mode, k):
+    d = dk()
+    parents, child = related_trio(rng, genome_len=4000, n_reads=150, read_len=120)
+    child = child + child[:40] + child[10:30]
+    with make_engine(mode, k=k, filter_log2_bits=22, n_hashes=4, seed=77, min_count=1) as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(parents)
+        kc = d.KmerCounter(eng)
+        parts = [kc.child_only(d.ReadBatch.from_sequences(eng, child[a:b]), ks)
+                 for a, b in ((0, 70), (70, 71), (71, 160), (160, len(child)))]
+        pseq, poff = orc.concat_reads(parents)
+        cseq, coff = orc.concat_reads(child)
+        f = orc.new_filter(22)
+        orc.bloom_insert(f, 22, 4, 77, k, True, pseq, poff)
+        for mc in (1, 2, 3):
+            merged = kc.merge(parts, min_count=mc)
+            km, cn, st = orc.bloom_probe(f, 22, 4, 77, k, True, cseq, coff, min_count=mc)
+            assert_result_equals(merged, km, cn)
+            assert merged.stats["n_distinct"] == st["n_distinct"] and merged.stats["n_emitted"] == len(km)
+        # merging nothing / a single table is the identity
+        assert len(kc.merge([], min_count=1)) == 0
+        one = kc.merge(parts[:1], min_count=1)
+        a, b = one.to_host(), parts[0].to_host()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
