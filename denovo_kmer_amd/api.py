@@ -308,6 +308,14 @@ class KmerSet:
         self.engine.check(self.engine._lib.dk_set_popcount(self._h, C.byref(n)))
         return int(n.value)
 
+    def save(self, path):
+        """write the filter (64-byte geometry header + bits) to `path`"""
+        self.engine.check(self.engine._lib.dk_set_save(self._h, str(path).encode()))
+
+    def load(self, path):
+        """read a filter written by save(); the file's geometry must match the engine's"""
+        self.engine.check(self.engine._lib.dk_set_load(self._h, str(path).encode()))
+
     @property
     def device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()

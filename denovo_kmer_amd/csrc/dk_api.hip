@@ -796,6 +796,86 @@ dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set)
     return DK_OK;
 }
 
+struct dk_filter_header {
+    char magic[8];                 // "DKBLOOM1"
+    uint32_t k, canonical, filter_log2_bits, n_hashes;
+    uint64_t seed;
+    uint64_t n_bytes;
+    uint8_t reserved[24];
+};
+static_assert(sizeof(dk_filter_header) == 64, "filter file header is 64 bytes");
+
+static dk_filter_header header_of(const dk_set *s)
+{
+    dk_filter_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "DKBLOOM1", 8);
+    h.k = s->e->cfg.k;
+    h.canonical = s->e->cfg.canonical;
+    h.filter_log2_bits = s->e->cfg.filter_log2_bits;
+    h.n_hashes = s->e->cfg.n_hashes;
+    h.seed = s->e->cfg.seed;
+    h.n_bytes = s->n_bytes;
+    return h;
+}
+
+dk_status dk_set_save(dk_set *s, const char *path)
+{
+    if (!s || !path) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(e, DK_ERR_INVALID_ARG, "cannot open %s for writing", path);
+    const dk_filter_header hd = header_of(s);
+    const size_t chunk = std::min<uint64_t>(s->n_bytes, 64ULL << 20);
+    void *buf = nullptr;
+    dk_status st = DK_OK;
+    if (hipHostMalloc(&buf, chunk, hipHostMallocDefault) != hipSuccess) st = fail(e, DK_ERR_OOM, "staging buffer allocation failed");
+    if (st == DK_OK && fwrite(&hd, sizeof hd, 1, f) != 1) st = fail(e, DK_ERR_INVALID_ARG, "write to %s failed", path);
+    for (uint64_t off = 0; st == DK_OK && off < s->n_bytes; off += chunk) {
+        const size_t nb = (size_t)std::min<uint64_t>(chunk, s->n_bytes - off);
+        hipError_t h = hipMemcpyAsync(buf, (const char *)s->d_words + off, nb, hipMemcpyDeviceToHost, e->stream);
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "reading the filter back failed: %s", hipGetErrorString(h));
+        else if (fwrite(buf, 1, nb, f) != nb) st = fail(e, DK_ERR_INVALID_ARG, "write to %s failed", path);
+    }
+    if (buf) (void)hipHostFree(buf);
+    if (fclose(f) != 0 && st == DK_OK) st = fail(e, DK_ERR_INVALID_ARG, "closing %s failed", path);
+    return st;
+}
+
+dk_status dk_set_load(dk_set *s, const char *path)
+{
+    if (!s || !path) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(e, DK_ERR_INVALID_ARG, "cannot open %s", path);
+    dk_filter_header hd;
+    const dk_filter_header want = header_of(s);
+    dk_status st = DK_OK;
+    if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, want.magic, 8) != 0)
+        st = fail(e, DK_ERR_INVALID_ARG, "%s is not a filter file", path);
+    else if (hd.k != want.k || hd.canonical != want.canonical || hd.filter_log2_bits != want.filter_log2_bits ||
+             hd.n_hashes != want.n_hashes || hd.seed != want.seed || hd.n_bytes != want.n_bytes)
+        st = fail(e, DK_ERR_INVALID_ARG, "%s was built with another geometry (k=%u log2_bits=%u n_hashes=%u)", path, hd.k,
+                  hd.filter_log2_bits, hd.n_hashes);
+    const size_t chunk = std::min<uint64_t>(s->n_bytes, 64ULL << 20);
+    void *buf = nullptr;
+    if (st == DK_OK && hipHostMalloc(&buf, chunk, hipHostMallocDefault) != hipSuccess)
+        st = fail(e, DK_ERR_OOM, "staging buffer allocation failed");
+    for (uint64_t off = 0; st == DK_OK && off < s->n_bytes; off += chunk) {
+        const size_t nb = (size_t)std::min<uint64_t>(chunk, s->n_bytes - off);
+        if (fread(buf, 1, nb, f) != nb) { st = fail(e, DK_ERR_INVALID_ARG, "%s is truncated", path); break; }
+        hipError_t h = hipMemcpyAsync((char *)s->d_words + off, buf, nb, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "uploading the filter failed: %s", hipGetErrorString(h));
+    }
+    if (buf) (void)hipHostFree(buf);
+    fclose(f);
+    return st;
+}
+
 dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src, uint64_t n_slices, uint64_t slice_bytes)
 {
     if (!e) return DK_ERR_INVALID_ARG;

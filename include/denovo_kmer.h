@@ -141,6 +141,11 @@ dk_status dk_set_device_ptr(dk_set *s, void **d_filter, uint64_t *n_bytes);
 dk_status dk_set_download(dk_set *s, uint64_t *words);               /* 2^n/64 words */
 dk_status dk_set_upload(dk_set *s, const uint64_t *words);
 dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set);
+/* on-disk parent filter (reuse the parents across children): 64-byte header with the geometry
+ * (k, canonical, filter_log2_bits, n_hashes, seed) followed by the 2^n/8 filter bytes.  dk_set_load
+ * refuses a file whose geometry differs from the engine's. */
+dk_status dk_set_save(dk_set *s, const char *path);
+dk_status dk_set_load(dk_set *s, const char *path);
 /* dst[i] |= src[j*slice_words + i] for j < n_slices: the local step of the OR-all-reduce
  * (RCCL has no bitwise-OR reduction; the host composes all-to-all -> this -> all-gather) */
 dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src,

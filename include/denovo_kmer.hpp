@@ -138,6 +138,8 @@ public:
         return n;
     }
     void clear() { check(dk_set_clear(s_), e_.get()); }
+    void save(const std::string &path) { check(dk_set_save(s_, path.c_str()), e_.get()); }
+    void load(const std::string &path) { check(dk_set_load(s_, path.c_str()), e_.get()); }
     dk_set *get() const { return s_; }
 
 private:

@@ -566,3 +566,25 @@ def test_result_merge_equals_whole_sample(rng, mode, k):
         one = kc.merge(parts[:1], min_count=1)
         a, b = one.to_host(), parts[0].to_host()
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_filter_save_and_load(tmp_path, rng):
+    d = dk()
+    reads = random_reads(rng, 200, 80, 140)
+    path = tmp_path / "parents.dkbloom"
+    with d.Engine(k=31, filter_log2_bits=23, n_hashes=4, seed=99) as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(reads)
+        words = ks.to_host()
+        ks.save(path)
+        assert path.stat().st_size == 64 + (1 << 23) // 8
+        ks2 = d.KmerSet(eng)
+        ks2.load(path)
+        assert np.array_equal(ks2.to_host(), words)
+    with d.Engine(k=31, filter_log2_bits=23, n_hashes=3, seed=99) as other:       # other geometry: refused
+        ks3 = d.KmerSet(other)
+        with pytest.raises(d.DkError) as ei:
+            ks3.load(path)
+        assert "geometry" in str(ei.value) and ks3.popcount() == 0
+        with pytest.raises(d.DkError):
+            ks3.load(tmp_path / "missing.dkbloom")

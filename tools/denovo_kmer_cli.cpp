@@ -1,0 +1,209 @@
+// denovo_kmer_cli.cpp -- command-line driver over include/denovo_kmer.hpp.
+//
+// Stands in for the reference's Rust CLI on the hot path only: reads come from FASTA / FASTQ /
+// one-sequence-per-line text (BAM/VCF I/O stays with the host tool, BASELINE.json north_star), the
+// parents go into the GPU-resident filter batch by batch, the child is probed batch by batch, the
+// per-batch tables are merged on the device and the child-only k-mers are written as TSV.
+//
+//   denovo_kmer_cli --k 31 --filter-log2 34 --parent p1.fq --parent p2.fq --child c.fq --out denovo.tsv
+//                   [--hashes 4] [--seed N] [--min-count 2] [--batch-reads 2000000] [--mode auto|direct|bucketed]
+//                   [--save-filter parents.dkbloom] [--load-filter parents.dkbloom] [--forward-only]
+//
+// Build: g++ -std=c++17 -O2 tools/denovo_kmer_cli.cpp -Ldenovo_kmer_amd -ldenovo_kmer -L/opt/rocm/lib -lamdhip64
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../include/denovo_kmer.hpp"
+
+namespace {
+
+// sequential reader of FASTA ('>'), FASTQ ('@') or plain lines; returns false at end of file
+class SeqReader {
+public:
+    explicit SeqReader(const std::string &path) : in_(path)
+    {
+        if (!in_) throw std::runtime_error("cannot open " + path);
+        const int c = in_.peek();
+        kind_ = c == '>' ? 'a' : c == '@' ? 'q' : 'p';
+    }
+    bool next(std::string &seq)
+    {
+        std::string line;
+        if (kind_ == 'p') {
+            while (std::getline(in_, line)) {
+                strip(line);
+                if (!line.empty()) { seq = line; return true; }
+            }
+            return false;
+        }
+        if (kind_ == 'q') {
+            std::string plus, qual;
+            if (!std::getline(in_, line)) return false;            // @name
+            if (!std::getline(in_, seq)) return false;
+            std::getline(in_, plus);
+            std::getline(in_, qual);
+            strip(seq);
+            return true;
+        }
+        // FASTA: a record may span lines
+        if (pending_.empty() && !std::getline(in_, pending_)) return false;
+        seq.clear();
+        while (std::getline(in_, line)) {
+            if (!line.empty() && line[0] == '>') { pending_ = line; return true; }
+            strip(line);
+            seq += line;
+        }
+        pending_.clear();
+        return !seq.empty() || in_.eof();
+    }
+
+private:
+    static void strip(std::string &s)
+    {
+        while (!s.empty() && (s.back() == '\r' || s.back() == '\n' || s.back() == ' ')) s.pop_back();
+    }
+    std::ifstream in_;
+    char kind_;
+    std::string pending_;
+};
+
+struct Args {
+    uint32_t k = 31, filter_log2 = 30, hashes = 4, min_count = 1, mode = DK_MODE_AUTO;
+    uint64_t seed = 0x5EED, batch_reads = 2000000;
+    bool canonical = true;
+    std::vector<std::string> parents;
+    std::string child, out, save_filter, load_filter;
+};
+
+[[noreturn]] void usage(const char *msg)
+{
+    std::fprintf(stderr, "%s\nusage: denovo_kmer_cli --k K --filter-log2 N --parent FILE [--parent FILE ...] --child FILE --out FILE\n"
+                         "       [--hashes 4] [--seed N] [--min-count 1] [--batch-reads 2000000] [--mode auto|direct|bucketed]\n"
+                         "       [--save-filter FILE] [--load-filter FILE] [--forward-only]\n", msg);
+    std::exit(2);
+}
+
+Args parse(int argc, char **argv)
+{
+    Args a;
+    for (int i = 1; i < argc; i++) {
+        const std::string f = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) usage(("missing value for " + f).c_str());
+            return argv[++i];
+        };
+        if (f == "--k") a.k = (uint32_t)std::stoul(val());
+        else if (f == "--filter-log2") a.filter_log2 = (uint32_t)std::stoul(val());
+        else if (f == "--hashes") a.hashes = (uint32_t)std::stoul(val());
+        else if (f == "--seed") a.seed = std::stoull(val());
+        else if (f == "--min-count") a.min_count = (uint32_t)std::stoul(val());
+        else if (f == "--batch-reads") a.batch_reads = std::stoull(val());
+        else if (f == "--parent") a.parents.push_back(val());
+        else if (f == "--child") a.child = val();
+        else if (f == "--out") a.out = val();
+        else if (f == "--save-filter") a.save_filter = val();
+        else if (f == "--load-filter") a.load_filter = val();
+        else if (f == "--forward-only") a.canonical = false;
+        else if (f == "--mode") {
+            const std::string m = val();
+            a.mode = m == "direct" ? DK_MODE_DIRECT : m == "bucketed" ? DK_MODE_BUCKETED : DK_MODE_AUTO;
+        } else usage(("unknown flag " + f).c_str());
+    }
+    if (a.child.empty() || a.out.empty()) usage("--child and --out are required");
+    if (a.parents.empty() && a.load_filter.empty()) usage("give --parent files or --load-filter");
+    if (a.batch_reads == 0) usage("--batch-reads must be positive");
+    return a;
+}
+
+std::string kmer_string(uint64_t hi, uint64_t lo, uint32_t k)
+{
+    std::string s(k, 'A');
+    for (uint32_t i = 0; i < k; i++) {
+        const uint32_t shift = 2 * (k - 1 - i);
+        const uint64_t code = shift >= 64 ? (hi >> (shift - 64)) & 3 : (lo >> shift) & 3;
+        s[i] = "ACGT"[code];
+    }
+    return s;
+}
+
+// feed a file to `fn` in batches of at most batch_reads sequences
+template <class Fn>
+uint64_t for_each_batch(const std::string &path, uint64_t batch_reads, Fn fn)
+{
+    SeqReader rd(path);
+    std::vector<std::string> batch;
+    std::string seq;
+    uint64_t n = 0;
+    while (rd.next(seq)) {
+        batch.push_back(seq);
+        n++;
+        if (batch.size() == batch_reads) { fn(batch); batch.clear(); }
+    }
+    if (!batch.empty()) fn(batch);
+    return n;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    const Args a = parse(argc, argv);
+    try {
+        dk_host::Config c;
+        c.k = a.k;
+        c.canonical = a.canonical;
+        c.filter_log2_bits = a.filter_log2;
+        c.n_hashes = a.hashes;
+        c.seed = a.seed;
+        c.min_count = 1;                 // thresholds apply to the merged counts
+        c.mode = a.mode;
+        dk_host::Engine eng(c);
+        dk_host::KmerSet parents(eng);
+        if (!a.load_filter.empty()) parents.load(a.load_filter);
+        uint64_t parent_windows = 0;
+        for (const std::string &p : a.parents) {
+            const uint64_t n = for_each_batch(p, a.batch_reads, [&](const std::vector<std::string> &b) {
+                parent_windows += parents.insert_sequences(b).n_windows;
+            });
+            std::fprintf(stderr, "parent %s: %llu reads\n", p.c_str(), (unsigned long long)n);
+        }
+        if (!a.save_filter.empty()) parents.save(a.save_filter);
+
+        dk_host::KmerCounter counter(eng);
+        std::vector<dk_result *> tables;
+        const uint64_t n_child = for_each_batch(a.child, a.batch_reads, [&](const std::vector<std::string> &b) {
+            dk_host::ReadBatch rb(eng, b);
+            tables.push_back(counter.child_only_device(rb, parents));
+        });
+        dk_host::KmerCounts res = counter.merge(tables, a.min_count);
+        for (dk_result *t : tables) dk_result_destroy(t);
+        std::fprintf(stderr, "child %s: %llu reads in %zu batch(es); %zu child-only k-mers with count >= %u (%llu distinct)\n",
+                     a.child.c_str(), (unsigned long long)n_child, tables.size(), res.size(), a.min_count,
+                     (unsigned long long)res.stats.n_distinct);
+
+        std::vector<size_t> order(res.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            return res.hi[x] != res.hi[y] ? res.hi[x] < res.hi[y] : res.lo[x] < res.lo[y];
+        });
+        std::ofstream out(a.out);
+        if (!out) throw std::runtime_error("cannot open " + a.out);
+        out << "kmer\tcount\n";
+        for (size_t i : order) out << kmer_string(res.hi[i], res.lo[i], a.k) << '\t' << res.count[i] << '\n';
+    } catch (const dk_host::Error &e) {
+        std::fprintf(stderr, "denovo_kmer error %d: %s\n", (int)e.status, e.what());
+        return 1;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
