@@ -157,6 +157,7 @@ struct SplitLds {
     uint32_t delta[MAX_BINS];   // index in the piece = stage index + delta[bin]  (mod 2^32)
     uint32_t cur[MAX_BINS];     // running fill of this workgroup's piece of each bin
     uint32_t total;
+    uint32_t ovf_seen;          // some bin of this workgroup has run past its capacity (never cleared)
 };
 
 
@@ -164,6 +165,7 @@ template <int THREADS, int PER_THREAD, class R>
 __device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD, R> &L, int nbins)
 {
     for (int i = (int)threadIdx.x; i < MAX_BINS; i += THREADS) { L.cnt[i] = 0; L.cur[i] = 0; }
+    if (threadIdx.x == 0) L.ovf_seen = 0;
     __syncthreads();
 }
 
@@ -198,6 +200,7 @@ __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD, R
             L.off[tid] = ex;
             L.delta[tid] = cu - ex;
             L.cur[tid] = cu + c;
+            if (cu + c > cap) L.ovf_seen = 1;
             if (tid == nbins - 1) L.total = ex + c;
         }
     }
@@ -211,13 +214,24 @@ __device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD, R
     lds_barrier();                                       // C
     st.mark(2);
     const uint32_t total = L.total;
+    if (!L.ovf_seen) {
+        // every bin still fits: no bounds check, no overflow ballot
 #pragma unroll 8
-    for (uint32_t i = tid; i < total; i += THREADS) {
-        const R rec = L.stage[i];
-        const uint32_t bin = bin_of(rec.h);
-        const uint32_t idx = i + L.delta[bin];
-        if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = rec;
-        ovf_append(ovf, idx >= cap, rec, n_overflow);
+        for (uint32_t i = tid; i < total; i += THREADS) {
+            const R rec = L.stage[i];
+            const uint32_t bin = bin_of(rec.h);
+            const uint32_t idx = i + L.delta[bin];       // 32-bit on purpose: delta is a wrapped difference
+            out[(bin_base + bin) * bin_stride + piece_off + idx] = rec;
+        }
+    } else {
+#pragma unroll 2
+        for (uint32_t i = tid; i < total; i += THREADS) {
+            const R rec = L.stage[i];
+            const uint32_t bin = bin_of(rec.h);
+            const uint32_t idx = i + L.delta[bin];
+            if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = rec;
+            ovf_append(ovf, idx >= cap, rec, n_overflow);
+        }
     }
     if (tid == 0) n_records += total;
     st.mark(3);
@@ -369,6 +383,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
     for (int i = tid; i < MAX_BINS; i += THREADS) L.cnt[i] = 0;
+    if (tid == 0) L.ovf_seen = 0;
     const R *src = in + piece * capw;
     R hs[PER_THREAD];
 #pragma unroll
@@ -392,9 +407,10 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     // scan (lane = bin) and reserve the segment ranges; the atomics' results are used after the scatter
     uint32_t *cursor = cursor2 + ((uint64_t)b << b2);
     const int wv = tid >> 6, lane = tid & 63;
-    uint32_t g = 0, ex = 0;
+    uint32_t g = 0, ex = 0, c_mine = 0;
     if (wv * 64 < nbins) {
         const uint32_t c = tid < nbins ? L.cnt[tid] : 0;
+        c_mine = c;
         uint32_t below = 0;
 #pragma unroll
         for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
@@ -413,18 +429,32 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++)
         if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j].h)] + rk[j]] = hs[j];
-    if (tid < nbins) L.delta[tid] = g - ex;
+    if (tid < nbins) {
+        L.delta[tid] = g - ex;
+        if (g + c_mine > cap2) L.ovf_seen = 1;
+    }
     lds_barrier();                                       // C
     const uint32_t total = L.total;
     const uint64_t seg0 = (uint64_t)b << b2;
     uint32_t n_overflow = 0;
+    if (!L.ovf_seen) {
+        // every segment region still has room for this tile: no bounds check, no overflow ballot
 #pragma unroll 4
-    for (uint32_t i = tid; i < total; i += THREADS) {
-        const R rec = L.stage[i];
-        const uint32_t bin = bin_of(rec.h);
-        const uint32_t idx = i + L.delta[bin];
-        if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = rec;
-        ovf_append(ovf, idx >= cap2, rec, n_overflow);
+        for (uint32_t i = tid; i < total; i += THREADS) {
+            const R rec = L.stage[i];
+            const uint32_t bin = bin_of(rec.h);
+            const uint32_t idx = i + L.delta[bin];       // 32-bit on purpose: delta is a wrapped difference
+            out[(seg0 + bin) * cap2 + idx] = rec;
+        }
+    } else {
+#pragma unroll 2
+        for (uint32_t i = tid; i < total; i += THREADS) {
+            const R rec = L.stage[i];
+            const uint32_t bin = bin_of(rec.h);
+            const uint32_t idx = i + L.delta[bin];
+            if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = rec;
+            ovf_append(ovf, idx >= cap2, rec, n_overflow);
+        }
     }
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
