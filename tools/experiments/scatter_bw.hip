@@ -1,0 +1,58 @@
+// scatter_bw.hip -- what HBM bandwidth does the multisplit WRITE PATTERN allow on its own?
+// Each block copies one tile of 8192 8-byte records; record i of tile t goes to region (i / run) % nbins
+// at slot t * run + i % run: runs of `run` records (run * 8 bytes contiguous) spread over nbins regions,
+// exactly the shape repart / scan_part produce, with no LDS work, no atomics.  run = 8192 is a plain copy.
+//   hipcc --offload-arch=gfx950 -O3 -o scatter_bw scatter_bw.hip && ./scatter_bw
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+__global__ void __launch_bounds__(1024) scatter_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                        uint32_t run, uint32_t nbins, uint64_t region_stride)
+{
+    const uint64_t t = blockIdx.x;
+    const uint64_t *src = in + t * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t i = j * 1024 + threadIdx.x;
+        const uint64_t v = src[i];
+        const uint32_t r = i / run, bin = r % nbins, rep = r / nbins;      // rep-th run of this tile in that bin
+        const uint64_t runs_per_tile_bin = (8192 / run + nbins - 1) / nbins;
+        out[bin * region_stride + (t * runs_per_tile_bin + rep) * run + i % run] = v;
+    }
+}
+
+int main()
+{
+    const uint64_t n = 1536ULL << 20;            // 1.61 G records = 12.9 GB
+    const uint32_t n_tiles = (uint32_t)(n / 8192);
+    uint64_t *in, *out;
+    hipMalloc(&in, n * 8);
+    hipMalloc(&out, (n + (64ULL << 20)) * 8 * 2);
+    hipMemset(in, 1, n * 8);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    const uint32_t runs[] = {8192, 256, 128, 64, 32, 16, 8};
+    for (uint32_t nbins : {128u, 256u, 32768u}) {
+        for (uint32_t run : runs) {
+            if (8192 / run < 1) continue;
+            const uint64_t runs_per_tile_bin = (8192 / run + nbins - 1) / nbins;
+            const uint64_t region_stride = (uint64_t)n_tiles * runs_per_tile_bin * run;
+            if (region_stride * nbins > (n + (64ULL << 20)) * 2) continue;
+            float best = 1e9f;
+            for (int it = 0; it < 3; it++) {
+                hipEventRecord(a);
+                scatter_kernel<<<n_tiles, 1024>>>(in, out, run, nbins, region_stride);
+                hipEventRecord(b);
+                hipEventSynchronize(b);
+                float ms;
+                hipEventElapsedTime(&ms, a, b);
+                if (ms < best) best = ms;
+            }
+            printf("nbins %6u run %5u records (%6u B): %.2f ms  %.2f TB/s (read+write)\n", nbins, run, run * 8, best,
+                   2.0 * n * 8 / best / 1e9);
+        }
+    }
+    return 0;
+}
