@@ -169,74 +169,6 @@ __device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD, R>
     __syncthreads();
 }
 
-// out index of record idx of bin: (bin_base + bin) * bin_stride + piece_off + idx.
-// `valid` has bit j set when hs[j] holds a record (already counted into L.cnt by the caller).
-template <int THREADS, int PER_THREAD, class R, class BinOf>
-__device__ __forceinline__ void multisplit_flush(SplitLds<THREADS, PER_THREAD, R> &L, const R (&hs)[PER_THREAD],
-                                                 const uint32_t (&rk)[PER_THREAD], uint32_t valid, int nbins, BinOf bin_of,
-                                                 uint64_t bin_base, uint64_t bin_stride, uint64_t piece_off,
-                                                 uint32_t cap, R *__restrict__ out, const OvfList<R> &ovf,
-                                                 uint32_t &n_records, uint32_t &n_overflow, Stamps &st)
-{
-    const int tid = (int)threadIdx.x;
-    st.mark(0);
-    // Parallel scan of the bin counts: lane = bin.  Each scanning wave sums the counts of the waves
-    // below it itself (independent LDS reads, one wave reduction), so no wave waits for another and
-    // the dependent LDS chain is one read deep.
-    const int wv = tid >> 6, lane = tid & 63;
-    if (wv * 64 < nbins) {
-        const uint32_t c = tid < nbins ? L.cnt[tid] : 0;
-        const uint32_t cu = tid < nbins ? L.cur[tid] : 0;
-        uint32_t below = 0;
-#pragma unroll
-        for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
-            const uint32_t x = L.cnt[64 * v + lane];    // unconditional: the reads pipeline (cnt[] is zero beyond nbins)
-            below += v < wv ? x : 0u;
-        }
-        below = wave_total(below);
-        const uint32_t inc = wave_incl_scan(c);
-        const uint32_t ex = below + inc - c;
-        if (tid < nbins) {
-            L.off[tid] = ex;
-            L.delta[tid] = cu - ex;
-            L.cur[tid] = cu + c;
-            if (cu + c > cap) L.ovf_seen = 1;
-            if (tid == nbins - 1) L.total = ex + c;
-        }
-    }
-    lds_barrier();                                       // B
-    st.mark(1);
-    if (tid < nbins) L.cnt[tid] = 0;                     // every scanning wave has read it
-    // rk[j] = rank of the record inside its bin for this tile (from the counting atomic)
-#pragma unroll
-    for (int j = 0; j < PER_THREAD; j++)
-        if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j].h)] + rk[j]] = hs[j];
-    lds_barrier();                                       // C
-    st.mark(2);
-    const uint32_t total = L.total;
-    if (!L.ovf_seen) {
-        // every bin still fits: no bounds check, no overflow ballot
-#pragma unroll 8
-        for (uint32_t i = tid; i < total; i += THREADS) {
-            const R rec = L.stage[i];
-            const uint32_t bin = bin_of(rec.h);
-            const uint32_t idx = i + L.delta[bin];       // 32-bit on purpose: delta is a wrapped difference
-            out[(bin_base + bin) * bin_stride + piece_off + idx] = rec;
-        }
-    } else {
-#pragma unroll 2
-        for (uint32_t i = tid; i < total; i += THREADS) {
-            const R rec = L.stage[i];
-            const uint32_t bin = bin_of(rec.h);
-            const uint32_t idx = i + L.delta[bin];
-            if (idx < cap) out[(bin_base + bin) * bin_stride + piece_off + idx] = rec;
-            ovf_append(ovf, idx >= cap, rec, n_overflow);
-        }
-    }
-    if (tid == 0) n_records += total;
-    st.mark(3);
-}
-
 // piece sizes, once per workgroup: cnt_out[(bin_base + bin) * n_pieces + piece] = min(fill, cap)
 template <int THREADS, int PER_THREAD, class R>
 __device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD, R> &L, int nbins, uint64_t bin_base,
@@ -254,6 +186,12 @@ __device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD, 
 // Thread t of a tile owns PER_THREAD consecutive positions: two (k > 32: three) bases words and two
 // mask words, prefetched from HBM one tile ahead straight to registers, cover all its windows, which
 // are produced by shifting one register group; the reverse complement rolls.
+//
+// Per tile: count (hash every window, LDS atomic gives its rank in its bin) | A | scan (lane = bin,
+// DPP; advances the workgroup's private cursors) | B | scatter into the LDS stage | C | copy-out of
+// the stage as per-bin runs.  The copy-out of tile i (LDS reads + global stores) is interleaved,
+// record by record, with the count phase of tile i+1 (pure VALU + one LDS atomic), so the LDS and
+// store latency of one hides behind the hashing of the other inside every wave.
 template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
@@ -263,6 +201,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     using R = typename RecOf<WIDE>::type;
     constexpr int TILE = THREADS * PER_THREAD;
     static_assert(PER_THREAD % 8 == 0 && PER_THREAD <= (WIDE ? 8 : 16), "a thread's positions must stay inside its bases words");
+    static_assert(THREADS * PER_THREAD <= 65536, "ranks are kept in 16 bits");
     __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
     const int nbins = 1 << b1;
@@ -285,72 +224,156 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     const int sk = (WIDE ? 128 : 64) - 2 * k;            // right-alignment shift of a window
     const uint64_t kmask_shift = 64 - k;
     const uint64_t G = gridDim.x, w = blockIdx.x;
-    uint64_t nw0 = 0, nw1 = 0, nw2 = 0, nm0 = 0, nm1 = 0;
-    if (blockIdx.x < n_tiles) load_words(blockIdx.x, nw0, nw1, nw2, nm0, nm1);
+    const uint64_t piece_base = w * capw, bin_stride = G * capw;
 
-#pragma unroll 1
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t w0 = nw0, w1 = nw1, w2 = nw2, m0 = nm0, m1 = nm1;
-        if (tile + gridDim.x < n_tiles) load_words(tile + gridDim.x, nw0, nw1, nw2, nm0, nm1);
-        const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
-        // left-align the stream at p0: bases in (v0, v1[, v2]), flags in (mh, ml)
+    // the tile being hashed: stream left-aligned at p0 -- bases in (v0, v1[, v2]), flags in (mh, ml)
+    uint64_t p0 = 0, v0 = 0, v1 = 0, v2 = 0, mh = 0, ml = 0, rch = 0, rcl = 0;
+    auto prep = [&](uint32_t tile, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t m0, uint64_t m1) {
+        p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
         const int o = 2 * (int)(p0 & 31);                 // PER_THREAD 8: 0,16,32,48; 16: 0,32
-        const uint64_t v0 = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
-        const uint64_t v1 = o ? (w1 << o) | (WIDE ? w2 >> (64 - o) : 0) : w1;
-        const uint64_t v2 = WIDE ? (o ? w2 << o : w2) : 0;
+        v0 = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
+        v1 = o ? (w1 << o) | (WIDE ? w2 >> (64 - o) : 0) : w1;
+        v2 = WIDE ? (o ? w2 << o : w2) : 0;
         const int ms = (int)(p0 & 63);
-        const uint64_t mh = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
-        const uint64_t ml = WIDE ? (ms ? m1 << ms : m1) : 0;
+        mh = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
+        ml = WIDE ? (ms ? m1 << ms : m1) : 0;
+    };
+    // window j of the tile being hashed -> record; returns true when the window is a k-mer
+    auto window = [&](int j, R &rec) -> bool {
+        uint64_t kh = 0, kl;
+        bool bad;
+        if (!WIDE) {
+            const uint64_t win = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+            const uint64_t fwd = win >> sk;
+            if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
+            else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
+            bad = ((mh << j) >> kmask_shift) != 0;
+            kl = (canonical && rcl < fwd) ? rcl : fwd;
+        } else {
+            const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+            const uint64_t B = j ? (v1 << (2 * j)) | (v2 >> (64 - 2 * j)) : v1;
+            const uint64_t fh = sk ? A >> sk : A;
+            const uint64_t fl = sk ? (B >> sk) | (A << (64 - sk)) : B;
+            if (j == 0) {
+                const uint64_t th = ~rev_pairs64(fl), tl = ~rev_pairs64(fh);
+                rch = sk ? th >> sk : th;
+                rcl = sk ? (tl >> sk) | (th << (64 - sk)) : tl;
+            } else {
+                rcl = (rcl >> 2) | (rch << 62);
+                rch = (rch >> 2) | ((uint64_t)(3u - (uint32_t)(fl & 3)) << (2 * k - 2 - 64));
+            }
+            const uint64_t mx = j ? (mh << j) | (ml >> (64 - j)) : mh;
+            bad = (mx >> kmask_shift) != 0;
+            const bool use_rc = canonical && (rch < fh || (rch == fh && rcl < fl));
+            kh = use_rc ? rch : fh;
+            kl = use_rc ? rcl : fl;
+        }
+        rec.h = fmix64(kl ^ hash_tweak<WIDE>(kh, seed));
+        if constexpr (WIDE) rec.hi = kh;
+        return !bad && p0 + j < s.n_bases;
+    };
 
+    uint32_t tile = blockIdx.x;
+    if (tile < n_tiles) {
+        uint64_t nw0 = 0, nw1 = 0, nw2 = 0, nm0 = 0, nm1 = 0;
+        {
+            uint64_t w0, w1, w2, m0, m1;
+            load_words(tile, w0, w1, w2, m0, m1);
+            if (tile + gridDim.x < n_tiles) load_words(tile + gridDim.x, nw0, nw1, nw2, nm0, nm1);
+            prep(tile, w0, w1, w2, m0, m1);
+        }
         R hs[PER_THREAD];
-        uint32_t rk[PER_THREAD];
+        uint32_t rk[PER_THREAD / 2];                     // ranks are < TILE <= 2^16: two per register
         uint32_t valid = 0;
-        uint64_t rch = 0, rcl = 0;                        // rolling reverse complement (rch unused for k <= 32)
+        // count phase of the first tile
 #pragma unroll
         for (int j = 0; j < PER_THREAD; j++) {
-            uint64_t kh = 0, kl;
-            bool bad;
-            if (!WIDE) {
-                const uint64_t win = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
-                const uint64_t fwd = win >> sk;
-                if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
-                else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
-                bad = ((mh << j) >> kmask_shift) != 0;
-                kl = (canonical && rcl < fwd) ? rcl : fwd;
-            } else {
-                const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
-                const uint64_t B = j ? (v1 << (2 * j)) | (v2 >> (64 - 2 * j)) : v1;
-                const uint64_t fh = sk ? A >> sk : A;
-                const uint64_t fl = sk ? (B >> sk) | (A << (64 - sk)) : B;
-                if (j == 0) {
-                    const uint64_t th = ~rev_pairs64(fl), tl = ~rev_pairs64(fh);
-                    rch = sk ? th >> sk : th;
-                    rcl = sk ? (tl >> sk) | (th << (64 - sk)) : tl;
-                } else {
-                    rcl = (rcl >> 2) | (rch << 62);
-                    rch = (rch >> 2) | ((uint64_t)(3u - (uint32_t)(fl & 3)) << (2 * k - 2 - 64));
-                }
-                const uint64_t mx = j ? (mh << j) | (ml >> (64 - j)) : mh;
-                bad = (mx >> kmask_shift) != 0;
-                const bool use_rc = canonical && (rch < fh || (rch == fh && rcl < fl));
-                kh = use_rc ? rch : fh;
-                kl = use_rc ? rcl : fl;
-            }
-            R rec;
-            rec.h = fmix64(kl ^ hash_tweak<WIDE>(kh, seed));
-            if constexpr (WIDE) rec.hi = kh;
-            hs[j] = rec;
-            rk[j] = 0;
-            if (!bad && p0 + j < s.n_bases) {
+            uint32_t r = 0;
+            if (window(j, hs[j])) {
                 valid |= 1u << j;
-                rk[j] = atomicAdd(&L.cnt[bin_of(rec.h)], 1u);
+                r = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
             }
+            rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
             // keep the windows sequential: interleaving the hash chains costs ~40 VGPRs and with
             // them half the resident waves, which hide latency better than in-wave ILP does
             __builtin_amdgcn_sched_barrier(0);
         }
-        lds_barrier();                                   // A
-        multisplit_flush(L, hs, rk, valid, nbins, bin_of, 0, G * capw, w * capw, capw, out, ovf, n_records, n_overflow, st);
+#pragma unroll 1
+        for (;;) {
+            lds_barrier();                               // A: the tile's counts are complete
+            st.mark(0);
+            // scan of the bin counts, lane = bin; each scanning wave sums the waves below it itself
+            // (independent LDS reads, one DPP reduction), so no wave waits for another
+            const int wv = tid >> 6, lane = tid & 63;
+            if (wv * 64 < nbins) {
+                const uint32_t c = tid < nbins ? L.cnt[tid] : 0;
+                const uint32_t cu = tid < nbins ? L.cur[tid] : 0;
+                uint32_t below = 0;
+#pragma unroll
+                for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
+                    const uint32_t x = L.cnt[64 * v + lane];    // unconditional: the reads pipeline (cnt[] is zero beyond nbins)
+                    below += v < wv ? x : 0u;
+                }
+                below = wave_total(below);
+                const uint32_t ex = below + wave_incl_scan(c) - c;
+                if (tid < nbins) {
+                    L.off[tid] = ex;
+                    L.delta[tid] = cu - ex;
+                    L.cur[tid] = cu + c;
+                    if (cu + c > capw) L.ovf_seen = 1;
+                    if (tid == nbins - 1) L.total = ex + c;
+                }
+            }
+            lds_barrier();                               // B: offsets ready
+            st.mark(1);
+            if (tid < nbins) L.cnt[tid] = 0;             // every scanning wave has read it
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; j++)
+                if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j].h)] + ((rk[j / 2] >> (16 * (j & 1))) & 0xffffu)] = hs[j];
+            lds_barrier();                               // C: stage ready, cnt[] zero
+            st.mark(2);
+            const uint32_t total = L.total;
+            const bool checked = L.ovf_seen != 0;        // some piece may be full: bounds check + overflow list
+            const bool has_next = tile + gridDim.x < n_tiles;
+            if (has_next) {
+                const uint64_t w0 = nw0, w1 = nw1, w2 = nw2, m0 = nm0, m1 = nm1;
+                if (tile + 2 * gridDim.x < n_tiles) load_words(tile + 2 * gridDim.x, nw0, nw1, nw2, nm0, nm1);
+                prep(tile + gridDim.x, w0, w1, w2, m0, m1);
+            }
+            valid = 0;
+            // copy-out of this tile, interleaved with the count phase of the next one
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; j++) {
+                const uint32_t i = (uint32_t)j * THREADS + tid;
+                const bool mine = i < total;
+                R rec;
+                uint32_t bin = 0, idx = 0;
+                if (mine) {
+                    rec = L.stage[i];
+                    bin = bin_of(rec.h);
+                    idx = i + L.delta[bin];              // 32-bit on purpose: delta is a wrapped difference
+                }
+                if (has_next) {
+                    uint32_t r = 0;
+                    if (window(j, hs[j])) {
+                        valid |= 1u << j;
+                        r = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
+                    }
+                    rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
+                }
+                if (!checked) {
+                    if (mine) out[(uint64_t)bin * bin_stride + piece_base + idx] = rec;
+                } else {
+                    if (mine && idx < capw) out[(uint64_t)bin * bin_stride + piece_base + idx] = rec;
+                    ovf_append(ovf, mine && idx >= capw, rec, n_overflow);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (tid == 0) n_records += total;
+            st.mark(3);
+            if (!has_next) break;
+            tile += gridDim.x;
+        }
     }
     st.flush(ctr, 0);
     multisplit_finish(L, nbins, 0, (uint32_t)G, (uint32_t)w, capw, cnt1);
