@@ -19,6 +19,8 @@ DK_ERR_UNSUPPORTED = 5
 DK_ERR_OVERFLOW = 6
 
 MODE_AUTO, MODE_DIRECT, MODE_BUCKETED = 0, 1, 2
+SET_BLOOM, SET_EXACT = 0, 1
+ERR_SET_FULL = 7
 MAX_STAGES = 12
 ABI_VERSION = 1
 
@@ -33,7 +35,8 @@ class DkConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint64), ("k", C.c_uint32), ("canonical", C.c_uint32),
                 ("filter_log2_bits", C.c_uint32), ("n_hashes", C.c_uint32), ("seed", C.c_uint64),
                 ("min_count", C.c_uint32), ("device_id", C.c_int32), ("rank", C.c_uint32),
-                ("world_size", C.c_uint32), ("mode", C.c_uint32), ("stream", C.c_void_p)]
+                ("world_size", C.c_uint32), ("mode", C.c_uint32), ("set_kind", C.c_uint32),
+                ("stream", C.c_void_p)]
 
 
 class DkStats(C.Structure):

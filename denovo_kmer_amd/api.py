@@ -50,12 +50,13 @@ class Engine:
     """One GPU + one stream + the k-mer / filter geometry (dk_engine)."""
 
     def __init__(self, k=31, canonical=True, filter_log2_bits=30, n_hashes=4, seed=0x5EED,
-                 min_count=1, device_id=0, mode="auto", rank=0, world_size=1, stream=None):
+                 min_count=1, device_id=0, mode="auto", rank=0, world_size=1, stream=None, set_kind="bloom"):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         mode_id = {"auto": _lib.MODE_AUTO, "direct": _lib.MODE_DIRECT, "bucketed": _lib.MODE_BUCKETED}[mode]
+        kind_id = {"bloom": _lib.SET_BLOOM, "exact": _lib.SET_EXACT}[set_kind]
         cfg = DkConfig(C.sizeof(DkConfig), k, int(bool(canonical)), filter_log2_bits, n_hashes,
-                       seed & (2**64 - 1), min_count, device_id, rank, world_size, mode_id, stream)
+                       seed & (2**64 - 1), min_count, device_id, rank, world_size, mode_id, kind_id, stream)
         check(self._lib.dk_engine_create(C.byref(cfg), C.byref(self._h)))
         self.k = k
         self.canonical = bool(canonical)
@@ -65,6 +66,7 @@ class Engine:
         self.min_count = min_count
         self.device_id = device_id
         self.mode = mode
+        self.set_kind = set_kind          # "bloom": blocked Bloom filter; "exact": exact set (HashSet semantics)
 
     @property
     def handle(self):
@@ -257,10 +259,12 @@ class KmerCounts:
 
 
 class KmerSet:
-    """Parent k-mer set: a blocked Bloom filter resident in HBM (dk_set).
+    """Parent k-mer set resident in HBM (dk_set).  Mirrors counter.rs `KmerSet` (insert / contains).
 
-    Mirrors counter.rs `KmerSet` (insert / contains); membership has Bloom semantics: no false
-    negatives, false positives at the filter's rate."""
+    Engine(set_kind="bloom") (default): blocked Bloom filter -- no false negatives, false positives at
+    the filter's rate.  Engine(set_kind="exact"): exact set (HashSet semantics)
+    held as per-segment open-addressing tables in the same 2^filter_log2_bits bits; insert raises
+    DkError(status 7) when a segment is full, popcount() is the number of k-mers held."""
 
     def __init__(self, engine, device_ptr=None, keepalive=None):
         self.engine = engine

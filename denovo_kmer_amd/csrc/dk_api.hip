@@ -130,6 +130,9 @@ static StreamView view_of(const dk_reads *r)
     return s;
 }
 
+// exact sets: number of 64-KiB segments = 2^T
+static int exact_T_of(const dk_engine *e) { return (int)e->cfg.filter_log2_bits - 19; }
+
 static FilterView fview_of(const dk_engine *e, const dk_set *s)
 {
     FilterView f;
@@ -137,6 +140,7 @@ static FilterView fview_of(const dk_engine *e, const dk_set *s)
     f.log2_blocks = (int)e->cfg.filter_log2_bits - 9;
     f.n_hashes = (int)e->cfg.n_hashes;
     f.seed = e->cfg.seed;
+    f.exact_T = s && s->exact ? exact_T_of(e) : 0;
     return f;
 }
 
@@ -301,6 +305,7 @@ const char *dk_status_string(dk_status s)
     case DK_ERR_OOM: return "out of device memory";
     case DK_ERR_UNSUPPORTED: return "unsupported configuration";
     case DK_ERR_OVERFLOW: return "capacity overflow";
+    case DK_ERR_SET_FULL: return "exact set full";
     default: return "unknown status";
     }
 }
@@ -320,6 +325,7 @@ dk_status dk_engine_create(const dk_config *cfg, dk_engine **out)
         return fail(nullptr, DK_ERR_INVALID_ARG, "n_hashes=%u outside 1..16", cfg->n_hashes);
     if (cfg->min_count < 1) return fail(nullptr, DK_ERR_INVALID_ARG, "min_count must be >= 1");
     if (cfg->mode > DK_MODE_BUCKETED) return fail(nullptr, DK_ERR_INVALID_ARG, "unknown mode %u", cfg->mode);
+    if (cfg->set_kind > DK_SET_EXACT) return fail(nullptr, DK_ERR_INVALID_ARG, "unknown set_kind %u", cfg->set_kind);
 
     int n_dev = 0;
     hipError_t r = hipGetDeviceCount(&n_dev);
@@ -630,11 +636,11 @@ dk_status dk_set_create(dk_engine *e, dk_set **out)
     s->n_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
     s->owns = true;
     s->d_words = nullptr;
+    s->exact = e->cfg.set_kind == DK_SET_EXACT;
     dk_status st = pool_alloc(e, s->n_bytes, (void **)&s->d_words);
     if (st != DK_OK) { delete s; return st; }
-    hipError_t h = hipMemsetAsync(s->d_words, 0, s->n_bytes, e->stream);
-    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
-    if (h != hipSuccess) { dk_set_destroy(s); return fail(e, DK_ERR_HIP, "clearing filter failed: %s", hipGetErrorString(h)); }
+    st = dk_set_clear(s);
+    if (st != DK_OK) { dk_set_destroy(s); return st; }
     *out = s;
     return DK_OK;
 }
@@ -649,6 +655,7 @@ dk_status dk_set_attach(dk_engine *e, void *d_filter, dk_set **out)
     s->e = e;
     s->n_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
     s->owns = false;
+    s->exact = e->cfg.set_kind == DK_SET_EXACT;
     s->d_words = (unsigned long long *)d_filter;
     *out = s;
     return DK_OK;
@@ -659,7 +666,16 @@ dk_status dk_set_clear(dk_set *s)
     if (!s) return DK_ERR_INVALID_ARG;
     dk_engine *e = s->e;
     DK_HIP(e, hipSetDevice(e->device));
-    DK_HIP(e, hipMemsetAsync(s->d_words, 0, s->n_bytes, e->stream));
+    if (s->exact) {
+        // an empty exact set is not all-zero: every slot holds its segment's EMPTY value
+        const uint64_t n_words = s->n_bytes / 8;
+        const int grid = grid_for(e, n_words / 2, DIRECT_BLOCK);
+        if (e->cfg.k > 32) exact_clear_kernel<true><<<grid, DIRECT_BLOCK, 0, e->stream>>>(s->d_words, n_words, exact_T_of(e));
+        else exact_clear_kernel<false><<<grid, DIRECT_BLOCK, 0, e->stream>>>(s->d_words, n_words, exact_T_of(e));
+        DK_HIP(e, hipGetLastError());
+    } else {
+        DK_HIP(e, hipMemsetAsync(s->d_words, 0, s->n_bytes, e->stream));
+    }
     DK_HIP(e, hipStreamSynchronize(e->stream));
     return DK_OK;
 }
@@ -669,6 +685,13 @@ static bool use_bucketed(const dk_engine *e, const dk_reads *r)
     if (e->cfg.mode == DK_MODE_DIRECT) return false;
     if (e->cfg.mode == DK_MODE_BUCKETED) return true;
     return dk::bucketed_pays(e, r->n_bases);
+}
+
+static dk_status set_full(dk_engine *e)
+{
+    return fail(e, DK_ERR_SET_FULL,
+                "exact set: %llu k-mer occurrences found no free slot in their 64-KiB segment; raise filter_log2_bits "
+                "(the set now holds a subset of the k-mers given)", (unsigned long long)e->h_ctr->n_set_full);
 }
 
 dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
@@ -683,6 +706,7 @@ dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
         bool direct = !use_bucketed(e, r);
         if (!direct) {
             const dk_status bs = dk::bucketed_insert(e, s, r);
+            if (bs == DK_OK && e->h_ctr->n_set_full) return set_full(e);
             if (bs == DK_ERR_OVERFLOW) {
                 // a bin overflowed (heavy-hitter k-mers): redo the batch with the direct family;
                 // records already ORed in are harmless
@@ -707,6 +731,7 @@ dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
     }
     DK_TRY(read_counters(e));
     DK_TRY(stage_end(e));
+    if (e->h_ctr->n_set_full) return set_full(e);
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->n_reads = r->n_reads;
@@ -788,8 +813,16 @@ dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set)
     DK_HIP(e, hipSetDevice(e->device));
     DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
     const uint64_t n_words = s->n_bytes / 8;
-    popcount_kernel<<<grid_for(e, n_words, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-        (const uint64_t *)s->d_words, n_words, &e->d_ctr->n_valid);
+    if (s->exact) {
+        const int grid = grid_for(e, n_words / 2, DIRECT_BLOCK);
+        if (e->cfg.k > 32)
+            exact_count_kernel<true><<<grid, DIRECT_BLOCK, 0, e->stream>>>(s->d_words, n_words, exact_T_of(e), &e->d_ctr->n_valid);
+        else
+            exact_count_kernel<false><<<grid, DIRECT_BLOCK, 0, e->stream>>>(s->d_words, n_words, exact_T_of(e), &e->d_ctr->n_valid);
+    } else {
+        popcount_kernel<<<grid_for(e, n_words, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            (const uint64_t *)s->d_words, n_words, &e->d_ctr->n_valid);
+    }
     DK_HIP(e, hipGetLastError());
     DK_TRY(read_counters(e));
     *n_bits_set = e->h_ctr->n_valid;
@@ -797,7 +830,7 @@ dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set)
 }
 
 struct dk_filter_header {
-    char magic[8];                 // "DKBLOOM1"
+    char magic[8];                 // "DKBLOOM1" | "DKEXACT1"
     uint32_t k, canonical, filter_log2_bits, n_hashes;
     uint64_t seed;
     uint64_t n_bytes;
@@ -809,11 +842,11 @@ static dk_filter_header header_of(const dk_set *s)
 {
     dk_filter_header h;
     memset(&h, 0, sizeof h);
-    memcpy(h.magic, "DKBLOOM1", 8);
+    memcpy(h.magic, s->exact ? "DKEXACT1" : "DKBLOOM1", 8);
     h.k = s->e->cfg.k;
     h.canonical = s->e->cfg.canonical;
     h.filter_log2_bits = s->e->cfg.filter_log2_bits;
-    h.n_hashes = s->e->cfg.n_hashes;
+    h.n_hashes = s->exact ? 0 : s->e->cfg.n_hashes;
     h.seed = s->e->cfg.seed;
     h.n_bytes = s->n_bytes;
     return h;
@@ -855,7 +888,7 @@ dk_status dk_set_load(dk_set *s, const char *path)
     const dk_filter_header want = header_of(s);
     dk_status st = DK_OK;
     if (fread(&hd, sizeof hd, 1, f) != 1 || memcmp(hd.magic, want.magic, 8) != 0)
-        st = fail(e, DK_ERR_INVALID_ARG, "%s is not a filter file", path);
+        st = fail(e, DK_ERR_INVALID_ARG, "%s is not a %s file", path, s->exact ? "DKEXACT1 exact-set" : "DKBLOOM1 filter");
     else if (hd.k != want.k || hd.canonical != want.canonical || hd.filter_log2_bits != want.filter_log2_bits ||
              hd.n_hashes != want.n_hashes || hd.seed != want.seed || hd.n_bytes != want.n_bytes)
         st = fail(e, DK_ERR_INVALID_ARG, "%s was built with another geometry (k=%u log2_bits=%u n_hashes=%u)", path, hd.k,

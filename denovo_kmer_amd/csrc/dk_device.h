@@ -114,6 +114,96 @@ __host__ __device__ __forceinline__ uint64_t bloom_block(uint64_t h, int log2_bl
     return log2_blocks > 0 ? (h >> (64 - log2_blocks)) : 0;
 }
 
+// ---- exact k-mer set -----------------------------
+// The same 2^n-bit array as the Bloom filter, read as open-addressing tables.  Segment s (64 KiB,
+// the unit the bucketed kernels stage in LDS) holds the keys whose hash starts with the
+// T = n - 19 bits of s: 8192 slots of one u64 (the hash, a bijection of the k-mer for k <= 32) or
+// 4096 slots of (hash, high word) for k > 32, probed linearly inside the segment from slot
+// (h >> 20).  EMPTY and LOCKED are values whose top T bits differ from the segment's, so no key of
+// the segment equals them.  A k > 32 slot is claimed EMPTY -> LOCKED, the high word is written, then
+// the hash is published, so a reader that sees the hash also sees its high word.
+constexpr int EXACT_SEG_WORDS = 8192;                     // u64 words per segment
+template <bool WIDE> struct ExactGeom { static constexpr uint32_t SLOTS = WIDE ? 4096 : 8192; };
+
+__host__ __device__ __forceinline__ uint64_t exact_empty(uint64_t seg, int T) { return (seg ^ 1ULL) << (64 - T); }
+__host__ __device__ __forceinline__ uint32_t exact_slot0(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 20) & mask; }
+
+// read-only lookup in one segment (LDS or HBM; no insert may be running)
+template <bool WIDE>
+__device__ __forceinline__ bool exact_find(const unsigned long long *seg, uint64_t EMPTY, uint64_t h, uint64_t hi)
+{
+    constexpr uint32_t MASK = ExactGeom<WIDE>::SLOTS - 1;
+    uint32_t slot = exact_slot0(h, MASK);
+    for (uint32_t t = 0; t <= MASK; t++) {
+        if constexpr (WIDE) {
+            const ulonglong2 v = *(const ulonglong2 *)(seg + 2 * slot);
+            if (v.x == h && v.y == hi) return true;
+            if (v.x == EMPTY) return false;
+        } else {
+            const unsigned long long v = seg[slot];
+            if (v == h) return true;
+            if (v == EMPTY) return false;
+        }
+        slot = (slot + 1) & MASK;
+    }
+    return false;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ bool exact_contains(const unsigned long long *table, int T, uint64_t h, uint64_t hi)
+{
+    const uint64_t seg = h >> (64 - T);
+    return exact_find<WIDE>(table + seg * EXACT_SEG_WORDS, exact_empty(seg, T), h, hi);
+}
+
+// insert-if-absent into one segment, concurrent with other inserts (never with exact_find).
+// SCOPE: __HIP_MEMORY_SCOPE_WORKGROUP for a segment staged in LDS, _AGENT for the table in HBM.
+// Returns 0 = already present, 1 = inserted, 2 = the segment has no free slot.
+// One loop, no inner spin: a lane that finds a slot LOCKED retries it on the next trip, by which
+// time the owner -- possibly a lane of the same wave, executing the other branch of this trip --
+// has published it.
+template <bool WIDE, int SCOPE>
+__device__ __forceinline__ int exact_insert(unsigned long long *seg, uint64_t EMPTY, uint64_t h, uint64_t hi)
+{
+    constexpr uint32_t SLOTS = ExactGeom<WIDE>::SLOTS, MASK = SLOTS - 1;
+    const unsigned long long LOCKED = EMPTY | 1ULL;
+    uint32_t slot = exact_slot0(h, MASK), t = 0;
+    int res = -1;
+    while (res < 0) {
+        unsigned long long *ph = seg + (WIDE ? 2 * slot : slot);
+        unsigned long long cur = __hip_atomic_load(ph, __ATOMIC_ACQUIRE, SCOPE);
+        if (cur == EMPTY) {
+            unsigned long long expect = EMPTY;
+            __hip_atomic_compare_exchange_strong(ph, &expect, WIDE ? LOCKED : (unsigned long long)h, __ATOMIC_ACQUIRE,
+                                                 __ATOMIC_ACQUIRE, SCOPE);
+            cur = expect;                                  // the value found
+            if (cur == EMPTY) {
+                if constexpr (WIDE) {
+                    __hip_atomic_store(ph + 1, (unsigned long long)hi, __ATOMIC_RELAXED, SCOPE);
+                    __hip_atomic_store(ph, (unsigned long long)h, __ATOMIC_RELEASE, SCOPE);
+                }
+                res = 1;
+                continue;
+            }
+        }
+        if (WIDE && cur == LOCKED) continue;               // being published: look again
+        if (cur == h && (!WIDE || __hip_atomic_load(ph + 1, __ATOMIC_RELAXED, SCOPE) == hi)) {
+            res = 0;
+        } else {
+            slot = (slot + 1) & MASK;
+            if (++t >= SLOTS) res = 2;
+        }
+    }
+    return res;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ int exact_insert_global(unsigned long long *table, int T, uint64_t h, uint64_t hi)
+{
+    const uint64_t seg = h >> (64 - T);
+    return exact_insert<WIDE, __HIP_MEMORY_SCOPE_AGENT>(table + seg * EXACT_SEG_WORDS, exact_empty(seg, T), h, hi);
+}
+
 // ---- wave-level helpers ---------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -44,6 +44,7 @@ struct dk_set {
     unsigned long long *d_words;
     uint64_t n_bytes;
     bool owns;
+    bool exact;                   // DK_SET_EXACT: d_words is read as open-addressing tables (dk_device.h)
 };
 
 struct dk_result {

@@ -645,6 +645,95 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     }
 }
 
+// ---- exact set: the segment is an open-addressing table (dk_device.h) -----------------------------
+// Same shape as seg_insert / seg_probe: segment -> LDS, one LDS operation chain per record, segment back.
+template <class R>
+__global__ void __launch_bounds__(SEG_THREADS)
+seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Counters *ctr)
+{
+    constexpr bool WIDE = sizeof(R) == 16;
+    static_assert(SEG_BYTES == EXACT_SEG_WORDS * 8, "exact segments are the filter segments");
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
+    const uint64_t seg_id = blockIdx.x;
+    const SegPieces<R> sp = seg_pieces(pl, seg_id);
+    const uint32_t n = sp.total();
+    if (n == 0) return;
+    load_segment((uint32_t *)tab, table, seg_id);
+    __syncthreads();
+    const uint64_t EMPTY = exact_empty(seg_id, T);
+    uint32_t n_full = 0;
+    constexpr int UNROLL = 4;
+    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
+        R rec[UNROLL];
+        bool have[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
+            have[u] = i < n;
+            rec[u] = sp.at(have[u] ? i : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+            if (have[u] && exact_insert<WIDE, __HIP_MEMORY_SCOPE_WORKGROUP>(tab, EMPTY, rec[u].h, rec_hi(rec[u])) == 2) n_full++;
+    }
+    __syncthreads();
+    uint4 *dst = (uint4 *)table + seg_id * (SEG_BYTES / 16);
+    const uint4 *s4 = (const uint4 *)tab;
+    for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += SEG_THREADS) dst[i] = s4[i];
+    n_full = (uint32_t)wave_sum(n_full);
+    if (lane_id() == 0 && n_full) atomicAdd(&ctr->n_set_full, (unsigned long long)n_full);
+}
+
+template <class R>
+__global__ void __launch_bounds__(SEG_THREADS)
+seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T,
+                       R *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
+{
+    constexpr bool WIDE = sizeof(R) == 16;
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
+    __shared__ uint32_t n_miss;
+    const uint64_t seg_id = blockIdx.x;
+    const SegPieces<R> sp = seg_pieces(pl, seg_id);
+    const uint32_t n = sp.total();
+    if (n == 0) {
+        if (threadIdx.x == 0) miss_cnt[seg_id] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) n_miss = 0;
+    load_segment((uint32_t *)tab, table, seg_id);
+    __syncthreads();
+    const uint64_t EMPTY = exact_empty(seg_id, T);
+    R *dst = miss + seg_id * miss_cap;
+    constexpr int UNROLL = 4;
+    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
+        R rec[UNROLL];
+        bool have[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
+            have[u] = i < n;
+            rec[u] = sp.at(have[u] ? i : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const bool absent = have[u] && !exact_find<WIDE>(tab, EMPTY, rec[u].h, rec_hi(rec[u]));
+            const uint64_t b = __ballot(absent);
+            if (b) {
+                const int leader = __ffsll((long long)b) - 1;
+                uint32_t wbase = 0;
+                if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
+                wbase = __shfl(wbase, leader);
+                if (absent) dst[wbase + popc_below(b)] = rec[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        miss_cnt[seg_id] = n_miss;
+        if (n_miss) atomicAdd(&ctr->n_absent, (unsigned long long)n_miss);
+    }
+}
+
 // Exact counting of one segment's absent records.
 // Most absent k-mers are singletons (sequencing errors), so a hash table for all of them is wasted
 // work.  Two 64-Kbit LDS bitmaps classify the records first: bit(h) set twice => the record MAY have
@@ -899,20 +988,28 @@ __device__ __forceinline__ bool ovf_filter_op(unsigned long long *filter, uint64
 // OR the overflow records into the filter (after seg_insert has written its segments back)
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-ovf_insert_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes)
+ovf_insert_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes, int exact_T, Counters *ctr)
 {
     unsigned long long n = *ovf.count;
     if (n > ovf.cap) n = ovf.cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        ovf_filter_op(filter, ovf.recs[i].h, log2_blocks, n_hashes, true);
+    uint32_t n_full = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const R rec = ovf.recs[i];
+        if (exact_T) {
+            if (exact_insert_global<sizeof(R) == 16>(filter, exact_T, rec.h, rec_hi(rec)) == 2) n_full++;
+        } else {
+            ovf_filter_op(filter, rec.h, log2_blocks, n_hashes, true);
+        }
+    }
+    if (n_full) atomicAdd(&ctr->n_set_full, (unsigned long long)n_full);
 }
 
 // Probe the overflow records (filter == nullptr: every record counts as absent); absent ones are
 // appended to `miss` and tallied per segment for the CSR build.
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes, int T,
+ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes, int exact_T, int T,
                  R *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
 {
     unsigned long long n = *ovf.count;
@@ -922,7 +1019,10 @@ ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, in
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool have = i < n;
         const R rec = ovf.recs[have ? i : 0];
-        const bool absent = have && (filter ? !ovf_filter_op(filter, rec.h, log2_blocks, n_hashes, false) : true);
+        bool absent = have;
+        if (have && filter)
+            absent = exact_T ? !exact_contains<sizeof(R) == 16>(filter, exact_T, rec.h, rec_hi(rec))
+                             : !ovf_filter_op(filter, rec.h, log2_blocks, n_hashes, false);
         const uint64_t slot = wave_append(absent, &ctr->n_ovf_miss);
         if (absent) {
             miss[slot] = rec;
@@ -1126,15 +1226,18 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     dk_status st = bucketed_partition<WIDE>(e, r, p, B);
     if (st == DK_OK) {
         const PieceList<R> pl{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
-        seg_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-            s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
+        if (s->exact)
+            seg_exact_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, p.T, e->d_ctr);
+        else
+            seg_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+                s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
         hipError_t h = hipGetLastError();
         if (h == hipSuccess) {
-            stage_mark(e, "seg_insert");
+            stage_mark(e, s->exact ? "seg_exact_insert" : "seg_insert");
             // overflow records (normally none): the kernel reads their number from device memory
             const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
             ovf_insert_kernel<R><<<e->n_cu * 2, DIRECT_BLOCK, 0, e->stream>>>(
-                s->d_words, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes);
+                s->d_words, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes, s->exact ? p.T : 0, e->d_ctr);
             h = hipGetLastError();
         }
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_insert launch failed: %s", hipGetErrorString(h));
@@ -1156,11 +1259,15 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     PieceList<R> list{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
-        seg_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-            s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+        if (s->exact)
+            seg_exact_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+                s->d_words, list, p.T, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+        else
+            seg_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+                s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
-        else stage_mark(e, "seg_probe");
+        else stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
         list = PieceList<R>{B.a, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
     }
     if (st == DK_OK) st = sync_counters(e, "bucketed probe");
@@ -1183,8 +1290,8 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
             h = hipMemsetAsync(B.extra_idx, 0, (3 * p.n_seg + 1) * 4, e->stream);
             if (h == hipSuccess) {
                 ovf_probe_kernel<R><<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                    s ? s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes, p.T,
-                    B.ovf_miss, hist, e->d_ctr);
+                    s ? s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes,
+                    s && s->exact ? p.T : 0, p.T, B.ovf_miss, hist, e->d_ctr);
                 ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)p.n_seg);
                 h = hipGetLastError();
             }

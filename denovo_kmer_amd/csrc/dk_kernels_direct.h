@@ -27,6 +27,7 @@ struct FilterView {
     int log2_blocks;             // log2_bits - 9
     int n_hashes;
     uint64_t seed;
+    int exact_T;                 // 0: blocked Bloom filter; > 0: exact table with 2^exact_T segments (dk_device.h)
 };
 
 struct Counters {               // device-side statistics of one operation
@@ -38,6 +39,7 @@ struct Counters {               // device-side statistics of one operation
     unsigned long long n_overflow;  // bucketed: records diverted to the overflow list
     unsigned long long n_ovf;       // bucketed: records appended to the overflow list
     unsigned long long n_ovf_miss;  // bucketed: overflow records absent from the filter
+    unsigned long long n_set_full;  // exact set: keys that found no free slot in their segment
     unsigned long long dbg[8];      // DK_STAMPS diagnostic builds only: per-phase cycle sums
     unsigned long long region_fill[32];   // bucketed seg_count: entries written to each output region
 };
@@ -255,13 +257,17 @@ __global__ void __launch_bounds__(DIRECT_BLOCK)
 insert_direct_kernel(StreamView s, FilterView f, int k, int canonical, Counters *ctr)
 {
     const GlobalWords W{s.bases, s.n_bwords - 1}, M{s.mask, s.n_mwords - 1};
-    uint64_t n_valid = 0;
+    uint64_t n_valid = 0, n_full = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < s.n_bases; p += stride) {
         Kmer km;
         if (!extract_kmer<WIDE>(p, k, canonical, W, M, km)) continue;
         n_valid++;
         const uint64_t h = hash_kmer<WIDE>(km, f.seed);
+        if (f.exact_T) {
+            if (exact_insert_global<WIDE>(f.words, f.exact_T, h, km.hi) == 2) n_full++;
+            continue;
+        }
         unsigned long long *blk = f.words + bloom_block(h, f.log2_blocks) * 8;
         const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
         for (int j = 0; j < f.n_hashes; j++) {
@@ -273,12 +279,15 @@ insert_direct_kernel(StreamView s, FilterView f, int k, int canonical, Counters 
         }
     }
     n_valid = wave_sum(n_valid);
+    n_full = wave_sum(n_full);
     if (lane_id() == 0 && n_valid) atomicAdd(&ctr->n_valid, (unsigned long long)n_valid);
+    if (lane_id() == 0 && n_full) atomicAdd(&ctr->n_set_full, (unsigned long long)n_full);
 }
 
 template <bool WIDE>
-__device__ __forceinline__ bool filter_test(const FilterView &f, uint64_t h)
+__device__ __forceinline__ bool filter_test(const FilterView &f, uint64_t h, uint64_t hi)
 {
+    if (f.exact_T) return exact_contains<WIDE>(f.words, f.exact_T, h, hi);
     const unsigned long long *blk = f.words + bloom_block(h, f.log2_blocks) * 8;
     const uint32_t a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
     bool all = true;
@@ -309,7 +318,7 @@ probe_direct_kernel(StreamView s, FilterView f, int k, int canonical, Counters *
         bool absent = false;
         if (valid) {
             n_valid++;
-            absent = f.words ? !filter_test<WIDE>(f, hash_kmer<WIDE>(km, f.seed)) : true;
+            absent = f.words ? !filter_test<WIDE>(f, hash_kmer<WIDE>(km, f.seed), km.hi) : true;
         }
         if (absent) n_absent++;
         app.push(absent, km.lo, km.hi, 0);
@@ -416,7 +425,7 @@ contains_kernel(FilterView f, const uint64_t *__restrict__ lo, const uint64_t *_
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Kmer km{WIDE ? hi[i] : 0, lo[i]};
-    out[i] = filter_test<WIDE>(f, hash_kmer<WIDE>(km, f.seed)) ? 1 : 0;
+    out[i] = filter_test<WIDE>(f, hash_kmer<WIDE>(km, f.seed), km.hi) ? 1 : 0;
 }
 
 // ---- filter utilities ---------------------------------------------------------------------------
@@ -442,6 +451,35 @@ popcount_kernel(const uint64_t *__restrict__ words, uint64_t n_words, unsigned l
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
         acc += (uint64_t)__popcll(words[i]);
+    acc = wave_sum(acc);
+    if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
+}
+
+// ---- exact set utilities --------------------------------------------------------------------------
+// every slot of every segment <- EMPTY of its segment (k > 32: high word 0); one thread per 16 bytes
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+exact_clear_kernel(unsigned long long *table, uint64_t n_words, int T)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words / 2; i += stride) {
+        const uint64_t e = exact_empty((2 * i) / EXACT_SEG_WORDS, T);
+        *(ulonglong2 *)(table + 2 * i) = ulonglong2{e, WIDE ? 0ULL : e};
+    }
+}
+
+// number of keys in the table
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+exact_count_kernel(const unsigned long long *__restrict__ table, uint64_t n_words, int T, unsigned long long *out)
+{
+    uint64_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words / 2; i += stride) {
+        const uint64_t e = exact_empty((2 * i) / EXACT_SEG_WORDS, T);
+        const ulonglong2 v = *(const ulonglong2 *)(table + 2 * i);
+        acc += (v.x != e) + (WIDE ? 0 : (v.y != e));
+    }
     acc = wave_sum(acc);
     if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
 }

@@ -45,10 +45,23 @@ enum {
     DK_ERR_HIP = 3,
     DK_ERR_OOM = 4,
     DK_ERR_UNSUPPORTED = 5,
-    DK_ERR_OVERFLOW = 6
+    DK_ERR_OVERFLOW = 6,
+    DK_ERR_SET_FULL = 7        /* exact set: a segment has no free slot left; raise filter_log2_bits */
 };
 
 enum { DK_MODE_AUTO = 0, DK_MODE_DIRECT = 1, DK_MODE_BUCKETED = 2 };
+
+/* What a dk_set holds in its 2^filter_log2_bits bits (both are HBM-resident and use the same kernels
+ * around them):
+ *  DK_SET_BLOOM  blocked Bloom filter (default): no false negatives, false positives at the
+ *                configured size, any number of k-mers.
+ *  DK_SET_EXACT  exact set -- what a HashSet<u64> gives: 64-KiB segments, each an open-addressing
+ *                table of the k-mers whose hash starts with the segment's bits (8 bytes per slot for
+ *                k <= 32, 16 bytes for k > 32).  Capacity 2^(n-6) k-mers (2^(n-7) for k > 32); size
+ *                it for a load of at most ~75 %.  dk_set_insert returns DK_ERR_SET_FULL when a k-mer
+ *                finds no free slot in its segment (the set then holds a subset of what was given).
+ *                n_hashes is ignored. */
+enum { DK_SET_BLOOM = 0, DK_SET_EXACT = 1 };
 
 typedef struct dk_engine dk_engine;
 typedef struct dk_reads dk_reads;     /* device-resident packed read batch */
@@ -66,6 +79,7 @@ typedef struct dk_config {
     int32_t  device_id;
     uint32_t rank, world_size;   /* informational; sharding is done by the host */
     uint32_t mode;               /* DK_MODE_* : kernel family for insert / probe */
+    uint32_t set_kind;           /* DK_SET_* : what the engine's sets hold (0 = Bloom filter) */
     void    *stream;             /* optional hipStream_t to run on; NULL = engine-owned stream */
 } dk_config;
 
@@ -132,7 +146,8 @@ uint64_t  dk_pack_ascii_host(const uint8_t *seq, const uint64_t *offsets, uint64
 
 /* ---- KmerSet (replaces: KmerSet in counter.rs -- insert / contains / union) ----------------- */
 dk_status dk_set_create(dk_engine *e, dk_set **out);                 /* zeroed, library-owned */
-dk_status dk_set_attach(dk_engine *e, void *d_filter, dk_set **out); /* caller-owned device memory of 2^n/8 bytes */
+dk_status dk_set_attach(dk_engine *e, void *d_filter, dk_set **out); /* caller-owned device memory of 2^n/8 bytes;
+                                                                        DK_SET_EXACT: call dk_set_clear before the first insert */
 dk_status dk_set_clear(dk_set *s);
 dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats);      /* KmerSet::insert over all windows */
 dk_status dk_set_contains(dk_set *s, const uint64_t *kmers_lo, const uint64_t *kmers_hi /* NULL if k<=32 */,
@@ -140,7 +155,7 @@ dk_status dk_set_contains(dk_set *s, const uint64_t *kmers_lo, const uint64_t *k
 dk_status dk_set_device_ptr(dk_set *s, void **d_filter, uint64_t *n_bytes);
 dk_status dk_set_download(dk_set *s, uint64_t *words);               /* 2^n/64 words */
 dk_status dk_set_upload(dk_set *s, const uint64_t *words);
-dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set);
+dk_status dk_set_popcount(dk_set *s, uint64_t *n_bits_set);          /* DK_SET_EXACT: the number of k-mers held */
 /* on-disk parent filter (reuse the parents across children): 64-byte header with the geometry
  * (k, canonical, filter_log2_bits, n_hashes, seed) followed by the 2^n/8 filter bytes.  dk_set_load
  * refuses a file whose geometry differs from the engine's. */

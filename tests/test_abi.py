@@ -55,8 +55,9 @@ def test_engine_create_rejects_bad_config():
     lib = _lib.load()
     h = C.c_void_p()
     for field, value in (("k", 0), ("k", 65), ("filter_log2_bits", 19), ("filter_log2_bits", 41),
-                         ("n_hashes", 0), ("n_hashes", 17), ("min_count", 0), ("mode", 9), ("struct_size", 8)):
-        cfg = _lib.DkConfig(C.sizeof(_lib.DkConfig), 31, 1, 24, 4, 1, 1, 0, 0, 1, 0, None)
+                         ("n_hashes", 0), ("n_hashes", 17), ("min_count", 0), ("mode", 9), ("set_kind", 2),
+                         ("struct_size", 8)):
+        cfg = _lib.DkConfig(C.sizeof(_lib.DkConfig), 31, 1, 24, 4, 1, 1, 0, 0, 1, 0, 0, None)
         setattr(cfg, field, value)
         assert lib.dk_engine_create(C.byref(cfg), C.byref(h)) == _lib.DK_ERR_INVALID_ARG, field
         assert not h.value
