@@ -45,6 +45,9 @@ def stage_algorithmic_bytes(stage, st, filter_bytes, read_len, k, geom=None):
         "seg_probe": 8.0 * nv + filter_bytes + 8.0 * na,   # records + one sweep of the filter + absent records out
         "seg_insert": 8.0 * nv + 2.0 * filter_bytes,       # records + filter read and written back
         "seg_count": 8.0 * na + 12.0 * nd,                 # absent records in, (k-mer, count) out
+        # exact set (--set-kind exact): the segments are hash tables, swept exactly like the filter
+        "seg_exact_probe": 8.0 * nv + filter_bytes + 8.0 * na,
+        "seg_exact_insert": 8.0 * nv + 2.0 * filter_bytes,
     }
     return table.get(stage)
 
@@ -89,6 +92,9 @@ def main():
     ap.add_argument("--n-hashes", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260313)
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "bucketed"])
+    ap.add_argument("--set-kind", default="bloom", choices=["bloom", "exact"],
+                    help="bloom: the headline metric's parent Bloom filter; exact: exact parent set (side measurement, "
+                         "--log2-bits then defaults to 36 + ceil(log2(gpus)))")
     ap.add_argument("--cpu-sample-reads", type=int, default=6_000_000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline; 0 = min(cores this process may use, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,7 +108,7 @@ def main():
     import torch.distributed as dist
 
     import denovo_kmer_amd as dk
-    from denovo_kmer_amd.dist import hip_or_fn, or_allreduce_
+    from denovo_kmer_amd.dist import local_reduce_fn, or_allreduce_
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,15 +130,17 @@ def main():
     on_host = args.backend == "gloo"          # reductions of scalars go through host tensors under gloo
 
     if args.log2_bits == 0:
-        args.log2_bits = 34 + max(0, (world - 1).bit_length())
+        args.log2_bits = (36 if args.set_kind == "exact" else 34) + max(0, (world - 1).bit_length())
     genome_len = args.genome * world
     gcfg = dk.synth_config(seed=args.seed, genome_len=genome_len, read_len=args.read_len)
     eng = dk.Engine(k=args.k, filter_log2_bits=args.log2_bits, n_hashes=args.n_hashes, seed=args.seed,
-                    device_id=local_rank, mode=args.mode, rank=rank, world_size=world)
+                    device_id=local_rank, mode=args.mode, rank=rank, world_size=world, set_kind=args.set_kind)
     filter_bytes = (1 << args.log2_bits) // 8
     filt = torch.zeros(filter_bytes // 8, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     kset = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
+    if args.set_kind == "exact":
+        kset.clear()                         # an empty exact set is not all-zero memory
     first = rank * args.reads
 
     # ---- parent build (once; reported, not part of `value`) ---------------------------------
@@ -150,7 +158,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        allreduce_bytes = or_allreduce_(filt, hip_or_fn(eng), stage_through_cpu=on_host)
+        allreduce_bytes = or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=on_host)
         torch.cuda.synchronize()
         dist.barrier()
         allreduce_ms = (time.perf_counter() - t0) * 1e3
@@ -217,16 +225,18 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Gk-mers/sec (child reads vs parent Bloom), k=%d" % args.k,
+            "metric": "Gk-mers/sec (child reads vs parent %s), k=%d" % ("Bloom" if args.set_kind == "bloom" else "exact set", args.k),
             "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[1]: k=%d, chr20-scale 30x synthetic trio, %d x %d bp reads per sample per GPU, "
-                                   "genome %d Mb, parent Bloom 2^%d bits resident in HBM"
-                                   % (args.k, args.reads, args.read_len, genome_len >> 20, args.log2_bits),
+                                   "genome %d Mb, parent %s 2^%d bits resident in HBM"
+                                   % (args.k, args.reads, args.read_len, genome_len >> 20,
+                                      "Bloom" if args.set_kind == "bloom" else "exact set (open-addressing tables)", args.log2_bits),
                        "k": args.k, "reads_per_gpu": args.reads, "read_len": args.read_len,
                        "filter_log2_bits": args.log2_bits, "n_hashes": args.n_hashes, "mode": args.mode,
-                       "parallelism": "reads sharded x%d, OR-all-reduce of parent filter" % world},
+                       "set_kind": args.set_kind,
+                       "parallelism": "reads sharded x%d, %s-all-reduce of parent set" % (world, "OR" if args.set_kind == "bloom" else "union")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stages[dom]},
@@ -238,7 +248,9 @@ def main():
                              "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes,
                              "filter_bits_set": popc, "filter_identical_on_all_ranks": filter_consistent},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.set_kind == "exact":
+            out["parent_build"]["exact_set_load"] = popc / (filter_bytes / (16 if args.k > 32 else 8))
+        if world == 1 and not args.no_cpu_baseline and args.set_kind == "bloom":
             out["cpu_baseline"] = cpu_baseline(dk, eng, kset, gcfg, args, min(args.cpu_sample_reads, args.reads))
         print(json.dumps(out), flush=True)
 

@@ -99,6 +99,7 @@ SYMBOLS = {
     "dk_set_save": (C.c_int32, [_P, C.c_char_p]),
     "dk_set_load": (C.c_int32, [_P, C.c_char_p]),
     "dk_or_reduce_slices": (C.c_int32, [_P, _P, _P, _U64, _U64]),
+    "dk_union_slices": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64]),
     "dk_set_destroy": (None, [_P]),
     "dk_probe": (C.c_int32, [_P, _P, _P, _PP, C.POINTER(DkStats)]),
     "dk_result_size": (C.c_int32, [_P, _PU64]),

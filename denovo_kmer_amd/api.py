@@ -90,6 +90,12 @@ class Engine:
         self.check(self._lib.dk_or_reduce_slices(self.handle, C.c_void_p(dst_ptr), C.c_void_p(src_ptr),
                                                  n_slices, slice_bytes))
 
+    def union_slices(self, dst_ptr, src_ptr, n_slices, slice_bytes, first_segment):
+        """exact sets: insert the keys of n_slices table slices at src into the slice at dst (device
+        pointers; all cover the 64-KiB segments from first_segment): local step of the union-all-reduce."""
+        self.check(self._lib.dk_union_slices(self.handle, C.c_void_p(dst_ptr), C.c_void_p(src_ptr),
+                                             n_slices, slice_bytes, first_segment))
+
     def close(self):
         if self._h:
             self._lib.dk_engine_destroy(self._h)

@@ -623,6 +623,13 @@ uint64_t dk_pack_ascii_host(const uint8_t *seq, const uint64_t *offsets, uint64_
     return p;
 }
 
+static dk_status set_full(dk_engine *e)
+{
+    return fail(e, DK_ERR_SET_FULL,
+                "exact set: %llu k-mer occurrences found no free slot in their 64-KiB segment; raise filter_log2_bits "
+                "(the set now holds a subset of the k-mers given)", (unsigned long long)e->h_ctr->n_set_full);
+}
+
 // ---- KmerSet -------------------------------------------------------------------------------------
 dk_status dk_set_create(dk_engine *e, dk_set **out)
 {
@@ -685,13 +692,6 @@ static bool use_bucketed(const dk_engine *e, const dk_reads *r)
     if (e->cfg.mode == DK_MODE_DIRECT) return false;
     if (e->cfg.mode == DK_MODE_BUCKETED) return true;
     return dk::bucketed_pays(e, r->n_bases);
-}
-
-static dk_status set_full(dk_engine *e)
-{
-    return fail(e, DK_ERR_SET_FULL,
-                "exact set: %llu k-mer occurrences found no free slot in their 64-KiB segment; raise filter_log2_bits "
-                "(the set now holds a subset of the k-mers given)", (unsigned long long)e->h_ctr->n_set_full);
 }
 
 dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
@@ -922,6 +922,32 @@ dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src, uint
         (uint4 *)d_dst, (const uint4 *)d_src, n_slices, vec);
     DK_HIP(e, hipGetLastError());
     DK_HIP(e, hipStreamSynchronize(e->stream));
+    return DK_OK;
+}
+
+dk_status dk_union_slices(dk_engine *e, void *d_dst, const void *d_src, uint64_t n_slices, uint64_t slice_bytes,
+                          uint64_t first_segment)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, e->cfg.set_kind == DK_SET_EXACT);
+    CHECK_ARG(e, d_dst != nullptr && (d_src != nullptr || n_slices == 0));
+    CHECK_ARG(e, slice_bytes % SEG_BYTES == 0);
+    CHECK_ARG(e, ((uintptr_t)d_dst & 15) == 0 && ((uintptr_t)d_src & 15) == 0);
+    const int T = exact_T_of(e);
+    const uint64_t n_seg = slice_bytes / SEG_BYTES;
+    CHECK_ARG(e, first_segment + n_seg <= (1ULL << T) && n_seg <= 0x7FFFFFFFULL);
+    if (n_slices == 0 || n_seg == 0) return DK_OK;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
+    if (e->cfg.k > 32)
+        union_slices_kernel<true><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
+            (unsigned long long *)d_dst, (const unsigned long long *)d_src, n_slices, slice_bytes / 8, first_segment, T, e->d_ctr);
+    else
+        union_slices_kernel<false><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
+            (unsigned long long *)d_dst, (const unsigned long long *)d_src, n_slices, slice_bytes / 8, first_segment, T, e->d_ctr);
+    DK_HIP(e, hipGetLastError());
+    DK_TRY(read_counters(e));
+    if (e->h_ctr->n_set_full) return set_full(e);
     return DK_OK;
 }
 

@@ -734,6 +734,42 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
     }
 }
 
+// Union of table slices, the exact-set counterpart of or_slices_kernel: segment (first_seg + blockIdx.x)
+// of dst is staged in LDS and every key of the same segment in each of the n_slices source slices is
+// inserted into it (slot positions differ between tables built in different orders, so OR-ing is not an option).
+template <bool WIDE>
+__global__ void __launch_bounds__(SEG_THREADS)
+union_slices_kernel(unsigned long long *dst, const unsigned long long *__restrict__ src, uint64_t n_slices,
+                    uint64_t slice_words, uint64_t first_seg, int T, Counters *ctr)
+{
+    __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
+    const uint64_t seg_local = blockIdx.x;
+    load_segment((uint32_t *)tab, dst, seg_local);
+    __syncthreads();
+    const uint64_t EMPTY = exact_empty(first_seg + seg_local, T);
+    uint32_t n_full = 0;
+    for (uint64_t j = 0; j < n_slices; j++) {
+        const unsigned long long *sseg = src + j * slice_words + seg_local * EXACT_SEG_WORDS;
+        for (uint32_t i = threadIdx.x; i < ExactGeom<WIDE>::SLOTS; i += SEG_THREADS) {
+            uint64_t h, hi = 0;
+            if constexpr (WIDE) {
+                const ulonglong2 v = *(const ulonglong2 *)(sseg + 2 * i);
+                h = v.x;
+                hi = v.y;
+            } else {
+                h = sseg[i];
+            }
+            if (h != EMPTY && exact_insert<WIDE, __HIP_MEMORY_SCOPE_WORKGROUP>(tab, EMPTY, h, hi) == 2) n_full++;
+        }
+    }
+    __syncthreads();
+    uint4 *out = (uint4 *)dst + seg_local * (SEG_BYTES / 16);
+    const uint4 *s4 = (const uint4 *)tab;
+    for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += SEG_THREADS) out[i] = s4[i];
+    n_full = (uint32_t)wave_sum(n_full);
+    if (lane_id() == 0 && n_full) atomicAdd(&ctr->n_set_full, (unsigned long long)n_full);
+}
+
 // Exact counting of one segment's absent records.
 // Most absent k-mers are singletons (sequencing errors), so a hash table for all of them is wasted
 // work.  Two 64-Kbit LDS bitmaps classify the records first: bit(h) set twice => the record MAY have

@@ -1,4 +1,4 @@
-"""Multi-GPU host logic: read sharding and the OR-all-reduce of the parent filter.
+"""Multi-GPU host logic: read sharding and the OR- (Bloom) / union- (exact set) all-reduce of the parent set.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  The hot path shards
 by reads with one exchange step: every rank builds a partial parent filter of the FULL size from
@@ -32,10 +32,28 @@ def hip_or_fn(engine):
     return fn
 
 
-def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
-    """In-place bitwise-OR all-reduce of `filt` (1-D int64 tensor, one per rank, equal sizes).
+def hip_union_fn(engine, group=None):
+    """local step for exact sets (Engine(set_kind="exact")): the slices are runs of 64-KiB table
+    segments and are merged key by key through the C ABI (dk_union_slices)"""
+    def fn(dst, src, n_slices):
+        torch.cuda.synchronize()
+        slice_bytes = dst.numel() * dst.element_size()
+        assert slice_bytes % 65536 == 0, "an exact set splits across ranks in whole 64-KiB segments"
+        first_segment = dist.get_rank(group) * (slice_bytes // 65536)     # rank r reduces slice r
+        engine.union_slices(dst.data_ptr(), src.data_ptr(), n_slices, slice_bytes, first_segment)
+    return fn
 
-    or_fn(dst, src, n_slices): dst |= OR of the n_slices contiguous slices in src.
+
+def local_reduce_fn(engine, group=None):
+    """the local reduction step that matches what the engine's sets hold"""
+    return hip_union_fn(engine, group) if engine.set_kind == "exact" else hip_or_fn(engine)
+
+
+def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
+    """In-place all-reduce of the parent set `filt` (1-D int64 tensor, one per rank, equal sizes):
+    bitwise OR for a Bloom filter (or_fn = hip_or_fn), key union for an exact set (hip_union_fn).
+
+    or_fn(dst, src, n_slices): dst <- dst combined with the n_slices contiguous slices in src.
     stage_through_cpu: move the payload through host memory around each collective (for rehearsing
     the GPU path over the gloo backend, which has no device all-to-all); the OR step still runs
     wherever `filt` lives.

@@ -165,6 +165,12 @@ dk_status dk_set_load(dk_set *s, const char *path);
  * (RCCL has no bitwise-OR reduction; the host composes all-to-all -> this -> all-gather) */
 dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src,
                               uint64_t n_slices, uint64_t slice_bytes);
+/* DK_SET_EXACT counterpart: d_dst holds the 64-KiB segments first_segment .. first_segment +
+ * slice_bytes/65536 of an exact set's table; the keys of the same segments in each of the n_slices
+ * slices at d_src are inserted into it (the local step of the union-all-reduce: all-to-all -> this
+ * -> all-gather).  DK_ERR_SET_FULL if a segment cannot take all keys. */
+dk_status dk_union_slices(dk_engine *e, void *d_dst, const void *d_src, uint64_t n_slices,
+                          uint64_t slice_bytes, uint64_t first_segment);
 void      dk_set_destroy(dk_set *s);
 
 /* ---- membership pass + KmerCounter (replaces: child loop of counter.rs) ---------------------- */

@@ -38,6 +38,7 @@ struct Config {
     uint32_t min_count = 1;
     int32_t device_id = 0;
     uint32_t mode = DK_MODE_AUTO;
+    uint32_t set_kind = DK_SET_BLOOM;      // DK_SET_EXACT: KmerSet is an exact set (HashSet semantics)
     void *stream = nullptr;
 };
 
@@ -56,6 +57,7 @@ public:
         cfg.device_id = c.device_id;
         cfg.world_size = 1;
         cfg.mode = c.mode;
+        cfg.set_kind = c.set_kind;
         cfg.stream = c.stream;
         check(dk_engine_create(&cfg, &e_), nullptr);
     }
@@ -106,7 +108,9 @@ struct KmerCounts {
     size_t size() const { return lo.size(); }
 };
 
-// counter.rs `KmerSet`: insert sequences, test membership (Bloom semantics: no false negatives)
+// counter.rs `KmerSet`: insert sequences, test membership.  Config::set_kind picks what it holds:
+// a blocked Bloom filter (no false negatives, tunable false positives) or an exact set
+// (insert throws Error{DK_ERR_SET_FULL} when the table is too small; popcount() = k-mers held)
 class KmerSet {
 public:
     explicit KmerSet(Engine &e) : e_(e) { check(dk_set_create(e.get(), &s_), e.get()); }

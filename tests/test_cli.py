@@ -64,3 +64,29 @@ def test_cli_matches_oracle(tmp_path, rng, k, mode):
                    check=True, capture_output=True, text=True)
     assert out2.read_text() == out.read_text()
     assert np.array_equal(np.fromfile(flt, dtype=np.uint64, offset=64), f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,mode", [(31, "bucketed"), (45, "direct")])
+def test_cli_exact_set_matches_exact_oracle(tmp_path, rng, k, mode):
+    exe = build(tmp_path)
+    parents, child = related_trio(rng, genome_len=3000, n_reads=90, read_len=110)
+    child = child + child[:30]
+    (tmp_path / "p.txt").write_text("\n".join(parents) + "\n")
+    (tmp_path / "c.txt").write_text("\n".join(child) + "\n")
+    out, flt = tmp_path / "out.tsv", tmp_path / "parents.dkexact"
+    base = [exe, "--k", str(k), "--filter-log2", "23", "--seed", "4242", "--min-count", "2", "--batch-reads", "41",
+            "--mode", mode, "--exact"]
+    r = subprocess.run(base + ["--parent", str(tmp_path / "p.txt"), "--child", str(tmp_path / "c.txt"), "--out", str(out),
+                               "--save-filter", str(flt)], check=True, capture_output=True, text=True)
+    pseq, poff = orc.concat_reads(parents)
+    cseq, coff = orc.concat_reads(child)
+    km, cn, _ = orc.exact_child_only(k, True, pseq, poff, cseq, coff, min_count=2)
+    expect = ["kmer\tcount"] + [f"{kmer_str(a['hi'], a['lo'], k)}\t{int(c)}" for a, c in zip(km, cn)]
+    assert out.read_text().strip().split("\n") == expect and len(expect) > 5
+    pk, _, _ = orc.count_reads(k, True, pseq, poff)
+    assert f"exact parent set: {len(pk)} k-mers" in r.stderr
+    out2 = tmp_path / "out2.tsv"
+    subprocess.run(base + ["--load-filter", str(flt), "--child", str(tmp_path / "c.txt"), "--out", str(out2)],
+                   check=True, capture_output=True, text=True)
+    assert out2.read_text() == out.read_text()

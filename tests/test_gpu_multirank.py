@@ -17,7 +17,7 @@ from oracle import orc
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, q):
+def _worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, set_kind, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -25,40 +25,40 @@ def _worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, q):
     import torch.distributed as dist
 
     import denovo_kmer_amd as dk
-    from denovo_kmer_amd.dist import hip_or_fn, merge_counts, or_allreduce_, shard_range
+    from denovo_kmer_amd.dist import local_reduce_fn, merge_counts, or_allreduce_, shard_range
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
         gcfg = dk.synth_config(genome_len=100_000)
         eng = dk.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=nh, seed=seed, device_id=0, mode=mode,
-                        rank=rank, world_size=world)
+                        rank=rank, world_size=world, set_kind=set_kind)
         filt = torch.zeros((1 << log2_bits) // 64, dtype=torch.int64, device="cuda:0")
         torch.cuda.synchronize()
         ks = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
+        if set_kind == "exact":
+            ks.clear()                       # an empty exact set is not all-zero memory
         lo, hi = shard_range(n_reads, rank, world)
         for s in (0, 1):
             ks.insert_reads(dk.ReadBatch.synth(eng, gcfg, s, lo, hi - lo))
-        or_allreduce_(filt, hip_or_fn(eng), stage_through_cpu=True)
+        or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=True)
+        n_keys = ks.popcount()
         res = dk.KmerCounter(eng).child_only(dk.ReadBatch.synth(eng, gcfg, 2, lo, hi - lo), ks)
         khi, klo, kcnt = res.to_host()
         mhi, mlo, mcnt = merge_counts(khi, klo, kcnt, min_count=1)
-        q.put((rank, filt.cpu().numpy().view(np.uint64).copy(), mhi, mlo, mcnt))
+        q.put((rank, filt.cpu().numpy().view(np.uint64).copy(), mhi, mlo, mcnt, n_keys))
         eng.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode", ["direct", "bucketed"])
-def test_two_ranks_one_gpu_match_whole_input_oracle(mode):
-    n_reads, k, log2_bits, nh, seed, world = 6000, 31, 24, 4, 31337, 2
+def _run(mode, set_kind, n_reads, k, log2_bits, nh, seed, world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_reads, k, log2_bits, nh, seed, mode, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_reads, k, log2_bits, nh, seed, mode, set_kind, q))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -66,6 +66,14 @@ def test_two_ranks_one_gpu_match_whole_input_oracle(mode):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    return outs
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["direct", "bucketed"])
+def test_two_ranks_one_gpu_match_whole_input_oracle(mode):
+    n_reads, k, log2_bits, nh, seed, world = 6000, 31, 24, 4, 31337, 2
+    outs = _run(mode, "bloom", n_reads, k, log2_bits, nh, seed, world)
     ocfg = orc.synth_cfg(genome_len=100_000)
     f = orc.new_filter(log2_bits)
     for smp in (0, 1):
@@ -73,6 +81,27 @@ def test_two_ranks_one_gpu_match_whole_input_oracle(mode):
         orc.bloom_insert(f, log2_bits, nh, seed, k, True, seq, off)
     cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
     km, cn, _ = orc.bloom_probe(f, log2_bits, nh, seed, k, True, cseq, coff)
-    for rank, filt, mhi, mlo, mcnt in outs:
+    for rank, filt, mhi, mlo, mcnt, _ in outs:
         assert np.array_equal(filt, f)
+        assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcnt, cn)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode,k", [("bucketed", 31), ("direct", 41)])
+def test_two_ranks_exact_set_union_matches_whole_input_oracle(mode, k):
+    """exact sets: the per-rank tables are united segment by segment (dk_union_slices) between the
+    all-to-all and the all-gather; every rank ends with the same table and the exact child-only set"""
+    n_reads, log2_bits, seed, world = 6000, 27, 31337, 2
+    outs = _run(mode, "exact", n_reads, k, log2_bits, 4, seed, world)
+    ocfg = orc.synth_cfg(genome_len=100_000)
+    pseq, poff = orc.synth_reads(ocfg, 0, 0, n_reads)
+    p1seq, p1off = orc.synth_reads(ocfg, 1, 0, n_reads)
+    allseq = np.concatenate([pseq, p1seq])
+    alloff = np.concatenate([poff, p1off[1:] + poff[-1]])
+    cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+    km, cn, _ = orc.exact_child_only(k, True, allseq, alloff, cseq, coff)
+    pk, _, _ = orc.count_reads(k, True, allseq, alloff)
+    assert np.array_equal(outs[0][1], outs[1][1])                 # same table on both ranks
+    for rank, table, mhi, mlo, mcnt, n_keys in outs:
+        assert n_keys == len(pk)
         assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcnt, cn)

@@ -8,6 +8,7 @@
 //   denovo_kmer_cli --k 31 --filter-log2 34 --parent p1.fq --parent p2.fq --child c.fq --out denovo.tsv
 //                   [--hashes 4] [--seed N] [--min-count 2] [--batch-reads 2000000] [--mode auto|direct|bucketed]
 //                   [--save-filter parents.dkbloom] [--load-filter parents.dkbloom] [--forward-only]
+//                   [--exact]   parents held as an exact set of 2^filter-log2 bits instead of a Bloom filter
 //
 // Build: g++ -std=c++17 -O2 tools/denovo_kmer_cli.cpp -Ldenovo_kmer_amd -ldenovo_kmer -L/opt/rocm/lib -lamdhip64
 #include <algorithm>
@@ -78,7 +79,7 @@ private:
 struct Args {
     uint32_t k = 31, filter_log2 = 30, hashes = 4, min_count = 1, mode = DK_MODE_AUTO;
     uint64_t seed = 0x5EED, batch_reads = 2000000;
-    bool canonical = true;
+    bool canonical = true, exact = false;
     std::vector<std::string> parents;
     std::string child, out, save_filter, load_filter;
 };
@@ -87,7 +88,7 @@ struct Args {
 {
     std::fprintf(stderr, "%s\nusage: denovo_kmer_cli --k K --filter-log2 N --parent FILE [--parent FILE ...] --child FILE --out FILE\n"
                          "       [--hashes 4] [--seed N] [--min-count 1] [--batch-reads 2000000] [--mode auto|direct|bucketed]\n"
-                         "       [--save-filter FILE] [--load-filter FILE] [--forward-only]\n", msg);
+                         "       [--save-filter FILE] [--load-filter FILE] [--forward-only] [--exact]\n", msg);
     std::exit(2);
 }
 
@@ -112,6 +113,7 @@ Args parse(int argc, char **argv)
         else if (f == "--save-filter") a.save_filter = val();
         else if (f == "--load-filter") a.load_filter = val();
         else if (f == "--forward-only") a.canonical = false;
+        else if (f == "--exact") a.exact = true;
         else if (f == "--mode") {
             const std::string m = val();
             a.mode = m == "direct" ? DK_MODE_DIRECT : m == "bucketed" ? DK_MODE_BUCKETED : DK_MODE_AUTO;
@@ -165,6 +167,7 @@ int main(int argc, char **argv)
         c.seed = a.seed;
         c.min_count = 1;                 // thresholds apply to the merged counts
         c.mode = a.mode;
+        c.set_kind = a.exact ? DK_SET_EXACT : DK_SET_BLOOM;
         dk_host::Engine eng(c);
         dk_host::KmerSet parents(eng);
         if (!a.load_filter.empty()) parents.load(a.load_filter);
@@ -176,6 +179,7 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "parent %s: %llu reads\n", p.c_str(), (unsigned long long)n);
         }
         if (!a.save_filter.empty()) parents.save(a.save_filter);
+        if (a.exact) std::fprintf(stderr, "exact parent set: %llu k-mers\n", (unsigned long long)parents.popcount());
 
         dk_host::KmerCounter counter(eng);
         std::vector<dk_result *> tables;
