@@ -96,7 +96,7 @@ dk_status stage_end(dk_engine *e)
     if (e->n_ev) (void)hipEventElapsedTime(&t.total_ms, e->ev[0], e->ev[e->n_ev]);
 #ifdef DK_STAMPS
     (void)hipMemcpy(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost);
-    fprintf(stderr, "DK_STAMPS scan[count,scan,scatter,copy]=%llu %llu %llu %llu repart=%llu %llu %llu %llu\n",
+    fprintf(stderr, "DK_STAMPS scan[count,scan,scatter,copy]=%llu %llu %llu %llu aux[4..7]=%llu %llu %llu %llu\n",
             e->h_ctr->dbg[0], e->h_ctr->dbg[1], e->h_ctr->dbg[2], e->h_ctr->dbg[3], e->h_ctr->dbg[4], e->h_ctr->dbg[5],
             e->h_ctr->dbg[6], e->h_ctr->dbg[7]);
 #endif

@@ -118,33 +118,35 @@ __host__ __device__ __forceinline__ uint64_t bloom_block(uint64_t h, int log2_bl
 // The same 2^n-bit array as the Bloom filter, read as open-addressing tables.  Segment s (64 KiB,
 // the unit the bucketed kernels stage in LDS) holds the keys whose hash starts with the
 // T = n - 19 bits of s: 8192 slots of one u64 (the hash, a bijection of the k-mer for k <= 32) or
-// 4096 slots of (hash, high word) for k > 32, probed linearly inside the segment from slot
-// (h >> 20).  EMPTY and LOCKED are values whose top T bits differ from the segment's, so no key of
+// 4096 slots of (hash, high word) for k > 32, probed linearly inside the segment.  EMPTY and LOCKED are values whose top T bits differ from the segment's, so no key of
 // the segment equals them.  A k > 32 slot is claimed EMPTY -> LOCKED, the high word is written, then
 // the hash is published, so a reader that sees the hash also sees its high word.
 constexpr int EXACT_SEG_WORDS = 8192;                     // u64 words per segment
 template <bool WIDE> struct ExactGeom { static constexpr uint32_t SLOTS = WIDE ? 4096 : 8192; };
 
 __host__ __device__ __forceinline__ uint64_t exact_empty(uint64_t seg, int T) { return (seg ^ 1ULL) << (64 - T); }
-__host__ __device__ __forceinline__ uint32_t exact_slot0(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 20) & mask; }
+// Probing runs over 32-byte buckets (4 slots; 2 for k > 32) from bucket (h >> 20): one pair of
+// 16-byte reads covers a whole bucket, so a lookup is one or two round trips even when its wave-mates
+// sit in long clusters, and a 32-byte HBM sector is used whole.
+constexpr uint32_t EXACT_BUCKETS = EXACT_SEG_WORDS / 4;
+__host__ __device__ __forceinline__ uint32_t exact_bucket0(uint64_t h) { return (uint32_t)(h >> 20) & (EXACT_BUCKETS - 1); }
 
 // read-only lookup in one segment (LDS or HBM; no insert may be running)
 template <bool WIDE>
 __device__ __forceinline__ bool exact_find(const unsigned long long *seg, uint64_t EMPTY, uint64_t h, uint64_t hi)
 {
-    constexpr uint32_t MASK = ExactGeom<WIDE>::SLOTS - 1;
-    uint32_t slot = exact_slot0(h, MASK);
-    for (uint32_t t = 0; t <= MASK; t++) {
+    uint32_t b = exact_bucket0(h);
+    for (uint32_t t = 0; t < EXACT_BUCKETS; t++) {
+        const ulonglong2 p = *(const ulonglong2 *)(seg + 4 * b), q = *(const ulonglong2 *)(seg + 4 * b + 2);
+        // keys are never removed, so inside a bucket the key cannot sit behind an EMPTY slot
         if constexpr (WIDE) {
-            const ulonglong2 v = *(const ulonglong2 *)(seg + 2 * slot);
-            if (v.x == h && v.y == hi) return true;
-            if (v.x == EMPTY) return false;
+            if ((p.x == h && p.y == hi) || (q.x == h && q.y == hi)) return true;
+            if (p.x == EMPTY || q.x == EMPTY) return false;
         } else {
-            const unsigned long long v = seg[slot];
-            if (v == h) return true;
-            if (v == EMPTY) return false;
+            if (p.x == h || p.y == h || q.x == h || q.y == h) return true;
+            if (p.x == EMPTY || p.y == EMPTY || q.x == EMPTY || q.y == EMPTY) return false;
         }
-        slot = (slot + 1) & MASK;
+        b = (b + 1) & (EXACT_BUCKETS - 1);
     }
     return false;
 }
@@ -159,15 +161,35 @@ __device__ __forceinline__ bool exact_contains(const unsigned long long *table, 
 // insert-if-absent into one segment, concurrent with other inserts (never with exact_find).
 // SCOPE: __HIP_MEMORY_SCOPE_WORKGROUP for a segment staged in LDS, _AGENT for the table in HBM.
 // Returns 0 = already present, 1 = inserted, 2 = the segment has no free slot.
-// One loop, no inner spin: a lane that finds a slot LOCKED retries it on the next trip, by which
-// time the owner -- possibly a lane of the same wave, executing the other branch of this trip --
-// has published it.
+// First a plain bucket scan: most inserts are repeats (30x coverage) and end there; it stops at the
+// first slot that is not a settled foreign key.  A stale value is harmless -- a key, once seen, stays,
+// and a slot seen free is re-examined atomically.  From that slot on, one slot at a time with atomics;
+// one loop, no inner spin: a lane that finds a slot LOCKED retries it on the next trip, by which time
+// the owner -- possibly a lane of the same wave, executing the other branch of this trip -- has
+// published it.
 template <bool WIDE, int SCOPE>
 __device__ __forceinline__ int exact_insert(unsigned long long *seg, uint64_t EMPTY, uint64_t h, uint64_t hi)
 {
-    constexpr uint32_t SLOTS = ExactGeom<WIDE>::SLOTS, MASK = SLOTS - 1;
+    constexpr uint32_t SLOTS = ExactGeom<WIDE>::SLOTS, MASK = SLOTS - 1, PER_BUCKET = WIDE ? 2 : 4;
     const unsigned long long LOCKED = EMPTY | 1ULL;
-    uint32_t slot = exact_slot0(h, MASK), t = 0;
+    uint32_t b = exact_bucket0(h), slot = 0;
+    bool open = false;
+    for (uint32_t t = 0; t < EXACT_BUCKETS && !open; t++) {
+        asm volatile("" ::: "memory");                     // re-read: other lanes are inserting
+        const ulonglong2 p = *(const ulonglong2 *)(seg + 4 * b), q = *(const ulonglong2 *)(seg + 4 * b + 2);
+        if constexpr (WIDE) {
+            if ((p.x == h && p.y == hi) || (q.x == h && q.y == hi)) return 0;
+            const bool f0 = (p.x | 1ULL) == LOCKED || p.x == h, f1 = (q.x | 1ULL) == LOCKED || q.x == h;
+            if (f0 || f1) { slot = PER_BUCKET * b + (f0 ? 0u : 1u); open = true; }
+        } else {
+            if (p.x == h || p.y == h || q.x == h || q.y == h) return 0;
+            const bool f0 = p.x == EMPTY, f1 = p.y == EMPTY, f2 = q.x == EMPTY, f3 = q.y == EMPTY;
+            if (f0 || f1 || f2 || f3) { slot = PER_BUCKET * b + (f0 ? 0u : f1 ? 1u : f2 ? 2u : 3u); open = true; }
+        }
+        b = (b + 1) & (EXACT_BUCKETS - 1);
+    }
+    if (!open) return 2;
+    uint32_t t = 0;
     int res = -1;
     while (res < 0) {
         unsigned long long *ph = seg + (WIDE ? 2 * slot : slot);

@@ -517,8 +517,28 @@ struct SegPieces {
     }
 };
 
+// the loads of seg_pieces, separable so that a persistent kernel can issue them one segment ahead
+struct SegCounts {
+    uint32_t c[MAX_R];
+    uint32_t o0, o1;
+};
+
 template <class R>
-__device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint64_t seg_id)
+__device__ __forceinline__ SegCounts seg_counts(const PieceList<R> &pl, uint64_t seg_id)
+{
+    SegCounts sc;
+#pragma unroll
+    for (int q = 0; q < MAX_R; q++) sc.c[q] = (uint32_t)q < pl.n_pieces ? pl.cnt[seg_id * pl.n_pieces + q] : 0u;
+    sc.o0 = sc.o1 = 0;
+    if (pl.extra) {
+        sc.o0 = pl.extra_off[seg_id];
+        sc.o1 = pl.extra_off[seg_id + 1];
+    }
+    return sc;
+}
+
+template <class R>
+__device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint64_t seg_id, const SegCounts &sc)
 {
     SegPieces<R> sp;
     sp.base = pl.recs + seg_id * pl.n_pieces * (uint64_t)pl.piece_cap;
@@ -527,20 +547,18 @@ __device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint6
 #pragma unroll
     for (int q = 0; q < MAX_R; q++) {
         sp.start[q] = acc;
-        if ((uint32_t)q < pl.n_pieces) {
-            uint32_t c = pl.cnt[seg_id * pl.n_pieces + q];
-            acc += c < pl.piece_cap ? c : pl.piece_cap;
-        }
+        acc += sc.c[q] < pl.piece_cap ? sc.c[q] : pl.piece_cap;
     }
     sp.start[MAX_R] = acc;
-    sp.extra = nullptr;
-    sp.n_extra = 0;
-    if (pl.extra) {
-        const uint32_t o0 = pl.extra_off[seg_id], o1 = pl.extra_off[seg_id + 1];
-        sp.extra = pl.extra + o0;
-        sp.n_extra = o1 - o0;
-    }
+    sp.extra = pl.extra ? pl.extra + sc.o0 : nullptr;
+    sp.n_extra = sc.o1 - sc.o0;
     return sp;
+}
+
+template <class R>
+__device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint64_t seg_id)
+{
+    return seg_pieces(pl, seg_id, seg_counts(pl, seg_id));
 }
 
 __device__ __forceinline__ void load_segment(uint32_t *seg, const unsigned long long *filter, uint64_t seg_id)
@@ -561,7 +579,7 @@ seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int
     if (n == 0) return;                       // nothing to add: leave the segment untouched
     load_segment(seg, filter, seg_id);
     __syncthreads();
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = 8;
     for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
         uint64_t h[UNROLL];
         bool have[UNROLL];
@@ -607,7 +625,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     load_segment(seg, filter, seg_id);
     __syncthreads();
     R *dst = miss + seg_id * miss_cap;
-    constexpr int UNROLL = 4;                 // records in flight per thread: loads first, then the LDS tests
+    constexpr int UNROLL = 8;                 // records in flight per thread: loads first, then the LDS tests
     for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
         R rec[UNROLL];
         bool have[UNROLL];
@@ -662,7 +680,7 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
     __syncthreads();
     const uint64_t EMPTY = exact_empty(seg_id, T);
     uint32_t n_full = 0;
-    constexpr int UNROLL = 4;
+    constexpr int UNROLL = 8;
     for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
         R rec[UNROLL];
         bool have[UNROLL];
@@ -684,54 +702,91 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
     if (lane_id() == 0 && n_full) atomicAdd(&ctr->n_set_full, (unsigned long long)n_full);
 }
 
+// Persistent, and one HBM round trip per segment: a workgroup walks segments blockIdx.x, +gridDim.x, ...;
+// the segment's table and its first RPT x 1024 records are fetched to registers together (the piece
+// sizes they depend on were fetched one segment ahead), then the table goes to LDS and the records
+// probe it.  With ~12 K records and 64 KiB of table per segment (2^17 segments at configs[1]) a
+// load -> barrier -> load -> probe chain per segment left the kernel latency bound.
 template <class R>
-__global__ void __launch_bounds__(SEG_THREADS)
-seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T,
+__global__ void __launch_bounds__(SEG_THREADS, 8)
+seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, uint64_t n_seg, int T,
                        R *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
 {
     constexpr bool WIDE = sizeof(R) == 16;
+    constexpr int RPT = WIDE ? 4 : 8;                        // records fetched with the table
+    constexpr int TV = SEG_BYTES / 16 / SEG_THREADS;           // 16-byte vectors of the table per thread
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
     __shared__ uint32_t n_miss;
-    const uint64_t seg_id = blockIdx.x;
-    const SegPieces<R> sp = seg_pieces(pl, seg_id);
-    const uint32_t n = sp.total();
-    if (n == 0) {
-        if (threadIdx.x == 0) miss_cnt[seg_id] = 0;
-        return;
-    }
-    if (threadIdx.x == 0) n_miss = 0;
-    load_segment((uint32_t *)tab, table, seg_id);
-    __syncthreads();
-    const uint64_t EMPTY = exact_empty(seg_id, T);
-    R *dst = miss + seg_id * miss_cap;
-    constexpr int UNROLL = 4;
-    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
-        R rec[UNROLL];
-        bool have[UNROLL];
+    const uint32_t tid = threadIdx.x;
+    uint32_t absent_total = 0;
+    Stamps st;
+    uint64_t seg_id = blockIdx.x;
+    if (seg_id >= n_seg) return;
+    SegCounts sc = seg_counts(pl, seg_id);
+    for (;;) {
+        const uint64_t next = seg_id + gridDim.x;
+        const SegPieces<R> sp = seg_pieces(pl, seg_id, sc);
+        if (next < n_seg) sc = seg_counts(pl, next);        // used on the next trip
+        const uint32_t n = sp.total();
+        if (n == 0) {
+            if (tid == 0) miss_cnt[seg_id] = 0;
+        } else {
+            uint4 tv[TV];
+            const uint4 *src = (const uint4 *)table + seg_id * (SEG_BYTES / 16);
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
-            have[u] = i < n;
-            rec[u] = sp.at(have[u] ? i : 0);
-        }
+            for (int q = 0; q < TV; q++) tv[q] = src[q * SEG_THREADS + tid];
+            R rec[RPT];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            const bool absent = have[u] && !exact_find<WIDE>(tab, EMPTY, rec[u].h, rec_hi(rec[u]));
-            const uint64_t b = __ballot(absent);
-            if (b) {
-                const int leader = __ffsll((long long)b) - 1;
-                uint32_t wbase = 0;
-                if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
-                wbase = __shfl(wbase, leader);
-                if (absent) dst[wbase + popc_below(b)] = rec[u];
+            for (int u = 0; u < RPT; u++) {
+                const uint32_t i = (uint32_t)u * SEG_THREADS + tid;
+                rec[u] = sp.at(i < n ? i : 0);
+            }
+            __syncthreads();                      // the previous segment's table and n_miss are no longer read
+            st.mark(0);
+            if (tid == 0) n_miss = 0;
+#pragma unroll
+            for (int q = 0; q < TV; q++) ((uint4 *)tab)[q * SEG_THREADS + tid] = tv[q];
+            __syncthreads();
+            st.mark(1);
+            const uint64_t EMPTY = exact_empty(seg_id, T);
+            R *dst = miss + seg_id * miss_cap;
+            auto test = [&](bool have, const R &r) {
+                const bool absent = have && !exact_find<WIDE>(tab, EMPTY, r.h, rec_hi(r));
+                const uint64_t b = __ballot(absent);
+                if (b) {
+                    const int leader = __ffsll((long long)b) - 1;
+                    uint32_t wbase = 0;
+                    if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
+                    wbase = __shfl(wbase, leader);
+                    if (absent) dst[wbase + popc_below(b)] = r;
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < RPT; u++) test((uint32_t)u * SEG_THREADS + tid < n, rec[u]);
+            constexpr int UNROLL = 4;
+            for (uint32_t i0 = RPT * SEG_THREADS; i0 < n; i0 += UNROLL * SEG_THREADS) {
+                R more[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + tid;
+                    more[u] = sp.at(i < n ? i : 0);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) test(i0 + (uint32_t)u * SEG_THREADS + tid < n, more[u]);
+            }
+            st.mark(2);
+            __syncthreads();
+            st.mark(3);
+            if (tid == 0) {
+                miss_cnt[seg_id] = n_miss;
+                absent_total += n_miss;
             }
         }
+        if (next >= n_seg) break;
+        seg_id = next;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        miss_cnt[seg_id] = n_miss;
-        if (n_miss) atomicAdd(&ctr->n_absent, (unsigned long long)n_miss);
-    }
+    st.flush(ctr, 4);
+    if (tid == 0 && absent_total) atomicAdd(&ctr->n_absent, (unsigned long long)absent_total);
 }
 
 // Union of table slices, the exact-set counterpart of or_slices_kernel: segment (first_seg + blockIdx.x)
@@ -1131,8 +1186,8 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
     p->n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
     const int v = scan_variant();
     // 16-byte records (k > 32): 512 threads x 8 positions so that the LDS stage stays at 64 KiB
-    p->tile = wide ? 512 * 8 : v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : 1024 * 8;
-    const int blocks_per_cu = wide ? 2 : v == 1 ? 1 : v == 3 ? 4 : 2;
+    p->tile = wide ? 512 * 8 : v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : v == 4 ? 256 * 16 : v == 5 ? 128 * 16 : v == 6 ? 1024 * 16 : 1024 * 8;
+    const int blocks_per_cu = wide ? 2 : v == 1 ? 1 : v == 3 ? 4 : v == 4 ? 4 : v == 5 ? 6 : v == 6 ? 1 : 2;
     const uint64_t n_tiles = (r->n_bases + p->tile - 1) / p->tile;
     if (n_tiles > 0xFFFFFFFFULL) return false;
     p->G = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n_tiles, 1), (uint64_t)e->n_cu * blocks_per_cu);
@@ -1227,6 +1282,9 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
         case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
         case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
         case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
+        case 4: DK_SCAN_LAUNCH(256, 16, 4); break;
+        case 5: DK_SCAN_LAUNCH(128, 16, 3); break;
+        case 6: DK_SCAN_LAUNCH(1024, 16, 4); break;
         default: DK_SCAN_LAUNCH(1024, 8, 8); break;
         }
         DK_HIP(e, hipGetLastError());
@@ -1296,8 +1354,8 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
         if (s->exact)
-            seg_exact_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, p.T, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+            seg_exact_probe_kernel<R><<<(unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 2), SEG_THREADS, 0, e->stream>>>(
+                s->d_words, list, p.n_seg, p.T, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         else
             seg_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
                 s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
