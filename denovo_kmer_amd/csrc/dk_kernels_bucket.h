@@ -1289,7 +1289,9 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
         }
         DK_HIP(e, hipGetLastError());
         stage_mark(e, "scan_part");
-        DK_REPART_LAUNCH(1024, 8, 8);
+        static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
+        if (rv == 1) DK_REPART_LAUNCH(1024, 16, 4);
+        else DK_REPART_LAUNCH(1024, 8, 8);
     }
 #undef DK_SCAN_LAUNCH
 #undef DK_REPART_LAUNCH

@@ -102,3 +102,85 @@ def test_or_allreduce_and_sharded_trio_world2():
         assert ok_collective
         assert np.array_equal(filt, f)                       # union of shards == whole
         assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcn, cn)
+
+
+# ---- exact sets: the same three collective steps with a key union as the local reduction ------------
+SEG_WORDS = 8192            # one 64-KiB table segment = 8192 u64 slots (k <= 32)
+
+
+def _cpu_union_fn(T):
+    """CPU stand-in for dk_union_slices (k <= 32): slot values whose top T bits equal the segment index
+    are keys, anything else is an empty slot; keys of the source slices go into free slots of dst."""
+    def fn(dst, src, n_slices):
+        sl = dst.numel()
+        assert sl % SEG_WORDS == 0
+        first_segment = dist.get_rank() * (sl // SEG_WORDS)
+        d = dst.numpy().view(np.uint64)
+        s = src.numpy().view(np.uint64)
+        for seg in range(sl // SEG_WORDS):
+            prefix = np.uint64(first_segment + seg)
+            dseg = d[seg * SEG_WORDS:(seg + 1) * SEG_WORDS]
+            have = set(int(x) for x in dseg[(dseg >> np.uint64(64 - T)) == prefix])
+            free = [i for i in range(SEG_WORDS) if (int(dseg[i]) >> (64 - T)) != int(prefix)]
+            for j in range(n_slices):
+                sseg = s[j * sl + seg * SEG_WORDS:j * sl + (seg + 1) * SEG_WORDS]
+                for x in sseg[(sseg >> np.uint64(64 - T)) == prefix]:
+                    if int(x) not in have:
+                        have.add(int(x))
+                        dseg[free.pop(0)] = x
+    return fn
+
+
+def _union_worker(rank, world, port, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_seg = 1 << T
+        rng = np.random.default_rng(500 + rank)
+        table = np.zeros(n_seg * SEG_WORDS, dtype=np.uint64)
+        keys = []
+        for seg in range(n_seg):
+            empty = np.uint64((seg ^ 1) << (64 - T))
+            table[seg * SEG_WORDS:(seg + 1) * SEG_WORDS] = empty
+            low = rng.choice(1 << 20, size=300, replace=False).astype(np.uint64) * np.uint64(rank % 2 + 1)   # overlapping key sets
+            ks = (np.uint64(seg) << np.uint64(64 - T)) | low
+            slots = rng.choice(SEG_WORDS, size=len(ks), replace=False)
+            table[seg * SEG_WORDS + slots] = ks
+            keys.append(ks)
+        t = torch.from_numpy(table.view(np.int64))
+        or_allreduce_(t, _cpu_union_fn(T))
+        q.put((rank, table.copy(), np.concatenate(keys)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_union_allreduce_of_exact_tables_world2():
+    world, T = 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_union_worker, args=(r, world, port, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted((q.get(timeout=200) for _ in range(world)), key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.unique(np.concatenate([o[2] for o in outs]))
+    assert np.array_equal(outs[0][1], outs[1][1])                 # every rank ends with the same table
+    table = outs[0][1]
+    seg_of_slot = np.arange(len(table)) // SEG_WORDS
+    is_key = (table >> np.uint64(64 - T)) == seg_of_slot.astype(np.uint64)
+    assert np.array_equal(np.sort(table[is_key]), want)           # exactly the union, each key once
+
+
+def test_local_reduce_fn_follows_the_set_kind():
+    from denovo_kmer_amd import dist as dkdist
+
+    class FakeEngine:
+        set_kind = "bloom"
+    assert dkdist.local_reduce_fn(FakeEngine()).__qualname__.startswith("hip_or_fn")
+    FakeEngine.set_kind = "exact"
+    assert dkdist.local_reduce_fn(FakeEngine()).__qualname__.startswith("hip_union_fn")
