@@ -52,6 +52,7 @@ struct BucketPlan {
     uint32_t capw, cap2;   // records per level-1 piece / per segment
     uint64_t n_max;        // upper bound on records of the batch
     int tile;              // positions per scan_part tile
+    int variant;           // scan_part geometry (see make_plan)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
@@ -1164,10 +1165,14 @@ inline uint32_t piece_capacity(double mean, double ratio)
     return (uint32_t)((uint64_t)(c + 1.0) + 1) & ~1u;
 }
 
-inline int scan_variant()
+// scan_part geometry: 2 = 512 threads x 16 positions, two workgroups per CU (default); 6 = 1024 x 16, one
+// per CU, for 2^16 segments and more -- with 256-512 level-1 bins the 8192-record tile leaves 16-32
+// records per run and half-empty level-1 pieces, which the 16384-record tile and half as many
+// workgroups repair (2^37 bits: 61 -> 76 Gk-mers/s).  DK_SCAN_VARIANT forces one (1, 3, 4, 5: experiments).
+inline int scan_variant(int T)
 {
-    static const int v = [] { const char *e = getenv("DK_SCAN_VARIANT"); return e ? atoi(e) : 2; }();
-    return v;
+    static const int forced = [] { const char *e = getenv("DK_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    return forced ? forced : T >= 16 ? 6 : 2;
 }
 
 inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
@@ -1184,7 +1189,7 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
     p->p2 = 1u << p->b2;
     p->n_seg = 1ULL << p->T;
     p->n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
-    const int v = scan_variant();
+    const int v = p->variant = scan_variant(p->T);
     // 16-byte records (k > 32): 512 threads x 8 positions so that the LDS stage stays at 64 KiB
     p->tile = wide ? 512 * 8 : v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : v == 4 ? 256 * 16 : v == 5 ? 128 * 16 : v == 6 ? 1024 * 16 : 1024 * 8;
     const int blocks_per_cu = wide ? 2 : v == 1 ? 1 : v == 3 ? 4 : v == 4 ? 4 : v == 5 ? 6 : v == 6 ? 1 : 2;
@@ -1278,7 +1283,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
         stage_mark(e, "scan_part");
         DK_REPART_LAUNCH(512, 8, 8);
     } else {
-        switch (scan_variant()) {
+        switch (p.variant) {
         case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
         case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
         case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
@@ -1342,6 +1347,12 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     if (st == DK_OK && e->h_ctr->n_ovf) stage_mark(e, "ovf_insert");
     free_bufs(e, B);
     return st;
+}
+
+inline uint64_t seg_count_mid_threshold()
+{
+    static const uint64_t v = [] { const char *e = getenv("DK_CNT_MID"); return e ? (uint64_t)atoll(e) : 3600ULL; }();
+    return v;
 }
 
 template <bool WIDE>
@@ -1430,9 +1441,14 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
                 const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 2);
                 seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
                     list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
-            } else if (per_seg >= 1500) {
+            } else if (per_seg >= (WIDE ? 1300u : seg_count_mid_threshold())) {
                 const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 6);
                 seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
+                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
+            } else if (per_seg >= (WIDE ? 600u : 1200u)) {
+                // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 12);
+                seg_count_kernel<256, 1024, 1024, WIDE><<<cgrid, 256, 0, e->stream>>>(
                     list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             } else {
                 const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 32);

@@ -588,3 +588,61 @@ def test_filter_save_and_load(tmp_path, rng):
         assert "geometry" in str(ei.value) and ks3.popcount() == 0
         with pytest.raises(d.DkError):
             ks3.load(tmp_path / "missing.dkbloom")
+
+
+# ---- kernel geometries picked by size: every seg_count geometry, every scan_part tile shape -----------
+
+@pytest.mark.parametrize("n_reads,k", [(30, 31), (140, 31), (330, 31), (700, 31), (20, 51), (50, 51), (90, 51), (200, 51), (420, 51)])
+def test_every_seg_count_geometry_counts_exactly(rng, n_reads, k):
+    # KmerCounter over a 2^22-bit geometry (8 segments): n_reads * ~120 records / 8 segments per segment
+    # walks the <128>, <256>, <512> and <1024>-thread count kernels (thresholds in bucketed_probe_t)
+    d = dk()
+    reads = random_reads(rng, n_reads, 150, 151)
+    reads = reads + reads[: n_reads // 3]                    # repeats: counts above 1
+    seq, off = orc.concat_reads(reads)
+    with make_engine("bucketed", k=k, filter_log2_bits=22, seed=99) as eng:
+        res = d.KmerCounter(eng).count_sequences(reads)
+        assert_family_ran(eng)
+        km, cn, st = orc.count_reads(k, True, seq, off)
+        assert_result_equals(res, km, cn)
+        assert res.stats["n_distinct"] == st["n_distinct"] and int(cn.max()) >= 2
+
+
+_VARIANT_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+import denovo_kmer_amd as d
+from conftest import related_trio
+from oracle import orc
+rng = np.random.default_rng(4242)
+parents, child = related_trio(rng, genome_len=30000, n_reads=900, read_len=140)
+for k in (31, 45):
+    pseq, poff = orc.concat_reads(parents); cseq, coff = orc.concat_reads(child)
+    f = orc.new_filter(24)
+    orc.bloom_insert(f, 24, 4, 7, k, True, pseq, poff)
+    km, cn, st = orc.bloom_probe(f, 24, 4, 7, k, True, cseq, coff)
+    with d.Engine(k=k, filter_log2_bits=24, n_hashes=4, seed=7, mode="bucketed") as eng:
+        ks = d.KmerSet(eng); ks.insert_sequences(parents)
+        assert np.array_equal(ks.to_host(), f)
+        res = d.KmerCounter(eng).child_only(d.ReadBatch.from_sequences(eng, child), ks)
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert names[:2] == ["scan_part", "repart"] and "overflow_redo" not in names, names
+        hi, lo, cnt = res.to_host()
+        assert np.array_equal(lo, km["lo"]) and np.array_equal(hi, km["hi"]) and np.array_equal(cnt, cn)
+print("variant ok")
+"""
+
+
+@pytest.mark.parametrize("scan_variant,repart_variant", [(6, 0), (1, 0), (3, 1), (4, 0), (5, 0)])
+def test_scan_part_tile_shapes_agree_with_the_oracle(scan_variant, repart_variant):
+    """The scan_part geometry is chosen from the number of segments (2 below 2^16 segments, 6 from there on);
+    the environment switches force each compiled shape on a small input so that all of them are checked
+    (the switch is read once per process, hence the subprocess)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, DK_SCAN_VARIANT=str(scan_variant), DK_REPART_VARIANT=str(repart_variant))
+    script = _VARIANT_SCRIPT.format(root=ROOT, tests=os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
