@@ -1205,6 +1205,10 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
     if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 cursors
     p->capw = piece_capacity(m1, 4.0);
     p->cap2 = piece_capacity(m2, 64.0);
+    // piece stride = an odd multiple of 128 B past a 4-KiB boundary: the workgroups of repart read the same
+    // tile of neighbouring pieces at the same time, and strides near a large power of two pile those reads
+    // onto few HBM channels (measured 2 % on the whole pass)
+    p->capw = (p->capw + 511) / 512 * 512 + 16;
     return true;
 }
 
