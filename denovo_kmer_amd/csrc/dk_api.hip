@@ -982,7 +982,10 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
     stage_begin(e);
     dk_status st = DK_OK;
     if (r->n_bases) {
-        bool direct = !use_bucketed(e, r);
+        // KmerCounter (no set) partitions by batch size, not by the filter geometry: the bucketed family
+        // pays from a few million positions on, whatever the engine's filter size
+        bool direct = s ? !use_bucketed(e, r)
+                        : e->cfg.mode == DK_MODE_DIRECT || (e->cfg.mode == DK_MODE_AUTO && r->n_bases < (1ULL << 22));
         if (!direct) {
             st = dk::bucketed_probe(e, s, r, res);
             if (st == DK_ERR_OVERFLOW) {

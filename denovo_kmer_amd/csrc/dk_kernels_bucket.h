@@ -1175,10 +1175,22 @@ inline int scan_variant(int T)
     return forced ? forced : T >= 16 ? 6 : 2;
 }
 
-inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p)
+// KmerCounter (no set): the segments are only counting units, so their number follows the batch, not the
+// filter -- about 5 K records each, which one seg_count workgroup holds in registers (46 K records per
+// segment at the filter's 2^15 segments took 750 ms at configs[1], 2^18 segments take 9)
+inline int count_segments_log2(uint64_t n_records)
+{
+    static const uint64_t per_seg = [] { const char *v = getenv("DK_COUNT_SEG"); return v ? (uint64_t)atoll(v) : 5000ULL; }();
+    int T = 1;
+    while (T < 2 * MAX_BIN_BITS && (n_records >> T) > per_seg) T++;
+    return T;
+}
+
+// T_override > 0: number of segment bits to use instead of the filter's
+inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0)
 {
     const bool wide = e->cfg.k > 32;
-    p->T = (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
+    p->T = T_override > 0 ? T_override : (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
     if (p->T < 1 || p->T > 2 * MAX_BIN_BITS) return false;
     static const int b1_up = [] { const char *v = getenv("DK_B1_UP"); return v ? atoi(v) : 0; }();
     p->b1 = (p->T + b1_up) / 2;
@@ -1364,7 +1376,9 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
 {
     using R = typename RecOf<WIDE>::type;
     BucketPlan p;
-    if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
+    const uint64_t n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
+    if (!make_plan(e, r, &p, s ? 0 : count_segments_log2(n_max)))
+        return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B);
     PieceList<R> list{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
