@@ -841,7 +841,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                  uint32_t *__restrict__ out_cnt, Counters *ctr)
 {
     using R = typename RecOf<WIDE>::type;
-    constexpr int CNT_RPT = WIDE ? 8 : 16;                 // records held per thread
+    constexpr int CNT_RPT = (WIDE && CNT_THREADS < 1024) ? 8 : 16;   // records held per thread (the 1024-thread geometry runs one workgroup per CU: 128 VGPRs)
     constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
     // k <= 32: the table key is the record's hash (EMPTY = a value outside this segment's prefix).
     // k > 32: the key is a 64-bit fingerprint of (h, hi) (EMPTY = 0); the slot's owner stores (h, hi)
@@ -923,6 +923,11 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 if (bm_b[w] & m) my_flagged++; else my_unique++;
             }
         }
+        auto flagged = [&](int, const R &rec) -> bool {
+            uint32_t w, m;
+            bit_of(rec, w, m);
+            return (bm_b[w] & m) != 0;
+        };
         const uint32_t emit_unique = min_count <= 1 ? 1u : 0u;
         const uint32_t wave_unique = wave_total(my_unique);          // uniform per wave
         (void)block_excl_scan(my_flagged, wave_sums, &total);
@@ -948,12 +953,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 if (!single) load_chunk(c);
 #pragma unroll
                 for (int u = 0; u < CNT_RPT; u++) {
-                    bool uniq = false;
-                    if (have(c, u)) {
-                        uint32_t w, m;
-                        bit_of(hv[u], w, m);
-                        uniq = !(bm_b[w] & m);
-                    }
+                    const bool uniq = have(c, u) && !flagged(u, hv[u]);
                     const uint64_t bal = __ballot(uniq);
                     if (uniq) {
                         const uint64_t pos = o + (uint64_t)popc_below(bal);
@@ -992,9 +992,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                         for (int u = 0; u < CNT_RPT; u++) {
                             if (!have(c, u)) continue;
                             const R rec = hv[u];
-                            uint32_t w, m;
-                            bit_of(rec, w, m);
-                            if (!(bm_b[w] & m)) continue;
+                            if (!flagged(u, rec)) continue;
                             const unsigned long long f = fp_of(rec);
                             const uint32_t rr = (uint32_t)((((f >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20);
                             if (rr != r) continue;
