@@ -720,6 +720,7 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
     __shared__ uint32_t n_miss;
     const uint32_t tid = threadIdx.x;
     uint32_t absent_total = 0;
+    uint64_t pending = ~0ULL;                                // segment whose miss count is still in n_miss
     Stamps st;
     uint64_t seg_id = blockIdx.x;
     if (seg_id >= n_seg) return;
@@ -742,9 +743,16 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
                 const uint32_t i = (uint32_t)u * SEG_THREADS + tid;
                 rec[u] = sp.at(i < n ? i : 0);
             }
-            __syncthreads();                      // the previous segment's table and n_miss are no longer read
+            __syncthreads();                      // the previous segment's probes are done: its table is free, its count final
             st.mark(0);
-            if (tid == 0) n_miss = 0;
+            if (tid == 0) {
+                if (pending != ~0ULL) {
+                    miss_cnt[pending] = n_miss;
+                    absent_total += n_miss;
+                }
+                n_miss = 0;
+            }
+            pending = seg_id;
 #pragma unroll
             for (int q = 0; q < TV; q++) ((uint4 *)tab)[q * SEG_THREADS + tid] = tv[q];
             __syncthreads();
@@ -776,17 +784,16 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
                 for (int u = 0; u < UNROLL; u++) test(i0 + (uint32_t)u * SEG_THREADS + tid < n, more[u]);
             }
             st.mark(2);
-            __syncthreads();
-            st.mark(3);
-            if (tid == 0) {
-                miss_cnt[seg_id] = n_miss;
-                absent_total += n_miss;
-            }
         }
         if (next >= n_seg) break;
         seg_id = next;
     }
     st.flush(ctr, 4);
+    __syncthreads();
+    if (tid == 0 && pending != ~0ULL) {
+        miss_cnt[pending] = n_miss;
+        absent_total += n_miss;
+    }
     if (tid == 0 && absent_total) atomicAdd(&ctr->n_absent, (unsigned long long)absent_total);
 }
 
