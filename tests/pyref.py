@@ -97,6 +97,22 @@ def child_only(parent_reads, child_reads, k, log2_bits, n_hashes, seed, canonica
     return sorted((v, c) for v, c in counts.items() if c >= min_count), bl
 
 
+def exact_child_only(parent_reads, child_reads, k, canonical=True, min_count=1):
+    """DK_SET_EXACT semantics: plain set difference with counts.
+    -> (sorted [(kmer, count)], number of distinct parent k-mers)"""
+    parents = set()
+    for r in parent_reads:
+        for ok, v in read_kmers(r, k, canonical):
+            if ok:
+                parents.add(v)
+    counts = {}
+    for r in child_reads:
+        for ok, v in read_kmers(r, k, canonical):
+            if ok and v not in parents:
+                counts[v] = counts.get(v, 0) + 1
+    return sorted((v, c) for v, c in counts.items() if c >= min_count), len(parents)
+
+
 def pack_reads(reads):
     """-> (bases words, mask words, n_bases) in the dk_reads format"""
     codes, flags = [], []

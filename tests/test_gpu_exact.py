@@ -72,6 +72,29 @@ def test_exact_trio_parity(rng, mode, k, log2_bits, canonical):
             assert not ks.contains((km["hi"], km["lo"])).any()
 
 
+def _golden_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "small_trios.json")) as f:
+        return json.load(f)["cases"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: c["name"])
+def test_exact_golden_vectors_on_gpu(case, mode):
+    d = dk()
+    with exact_engine(mode, k=case["k"], filter_log2_bits=23, seed=case["seed"], canonical=case["canonical"],
+                      min_count=case["min_count"]) as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(case["parents"])
+        assert ks.popcount() == case["parent_distinct"]
+        res = d.KmerCounter(eng).child_only(d.ReadBatch.from_sequences(eng, case["child"]), ks)
+        hi, lo, cnt = res.to_host(sort=True)
+        assert [[int(a), int(b), int(c)] for a, b, c in zip(hi, lo, cnt)] == case["exact_child_only"]
+        for key in ("n_reads", "n_windows", "n_valid", "n_absent", "n_distinct"):
+            assert res.stats[key] == case["exact_stats"][key], key
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_exact_is_a_superset_of_the_bloom_result(rng, mode):
     # a small, crowded Bloom filter loses child-only k-mers to false positives; the exact set loses none

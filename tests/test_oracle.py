@@ -227,6 +227,24 @@ def test_pyref_reproduces_golden(case):
         assert words[i] == w
 
 
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_exact_set_golden_by_oracle_and_pyref(case):
+    # DK_SET_EXACT expectations: C oracle and the Python set-difference restatement agree with the file
+    pseq, poff = orc.concat_reads(case["parents"])
+    cseq, coff = orc.concat_reads(case["child"])
+    km, cn, st = orc.exact_child_only(case["k"], case["canonical"], pseq, poff, cseq, coff, case["min_count"])
+    assert [[int(a["hi"]), int(a["lo"]), int(c)] for a, c in zip(km, cn)] == case["exact_child_only"]
+    assert st == case["exact_stats"]
+    assert len(orc.count_reads(case["k"], case["canonical"], pseq, poff)[0]) == case["parent_distinct"]
+    if case["name"] != "loaded_k25_h1":            # 45 000 k-mers of 25 bases: too slow for the string-based restatement
+        ref, n_parents = pyref.exact_child_only(case["parents"], case["child"], case["k"], case["canonical"], case["min_count"])
+        assert [[v >> 64, v & pyref.M64, c] for v, c in ref] == case["exact_child_only"]
+        assert n_parents == case["parent_distinct"]
+    # Bloom result is a subset of the exact one (no false negatives)
+    exact = {(hi, lo): c for hi, lo, c in case["exact_child_only"]}
+    assert all(exact.get((hi, lo)) == c for hi, lo, c in case["child_only"])
+
+
 # ---- synthetic generator --------------------------------------------------------------------------
 
 def test_synth_reads_are_deterministic_and_related():

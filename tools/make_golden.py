@@ -40,6 +40,9 @@ def case(name, parents, child, k, log2_bits, n_hashes, seed, canonical=True, min
         "child_only": [[int(a["hi"]), int(a["lo"]), int(c)] for a, c in zip(km, cn)],
         "exact_child_only_n": int(len(ekm)),
         "exact_stats": est,
+        # DK_SET_EXACT: the exact set difference and the number of distinct parent k-mers
+        "exact_child_only": [[int(a["hi"]), int(a["lo"]), int(c)] for a, c in zip(ekm, ecn)],
+        "parent_distinct": int(len(orc.count_reads(k, canonical, pseq, poff)[0])),
     }
 
 
