@@ -85,6 +85,7 @@ SYMBOLS = {
     "dk_reads_synth": (C.c_int32, [_P, C.POINTER(DkSynthConfig), C.c_int32, _U64, _U64, _PP]),
     "dk_reads_stats": (C.c_int32, [_P, C.POINTER(DkStats)]),
     "dk_reads_download": (C.c_int32, [_P, _P, _P]),
+    "dk_reads_kmers": (C.c_int32, [_P, _P, _P, _P, _P, _P, C.POINTER(DkStats)]),
     "dk_reads_destroy": (None, [_P]),
     "dk_pack_ascii_host": (_U64, [_P, _P, _U64, _P, _P]),
     "dk_set_create": (C.c_int32, [_P, _PP]),

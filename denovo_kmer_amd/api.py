@@ -184,6 +184,29 @@ class ReadBatch:
         self.engine.check(self.engine._lib.dk_reads_download(self._h, _vp(bases), _vp(mask)))
         return bases, mask, n
 
+    def kmers(self, hashes=True, into=None):
+        """kmer.rs stand-in: canonical k-mer (and hash) of every stream position (dk_reads_kmers).
+
+        -> dict(lo, hi, hash, not_kmer, stats); arrays are indexed by stream position (read i starts at
+        offsets[i] + i), not_kmer is the MSB-first bit mask of positions where no k-mer starts.
+        into: optional dict of device pointers (ints) {"lo", "hi", "hash", "not_kmer"} to write to instead
+        of host arrays (the caller owns n_bases * 8 bytes each, (n_bases + 63) // 64 * 8 for the mask)."""
+        n = self.stats()["n_bases"]
+        wide = self.engine.k > 32
+        out = {}
+        if into is None:
+            out["lo"] = np.zeros(n, dtype=np.uint64)
+            out["hi"] = np.zeros(n, dtype=np.uint64) if wide else None
+            out["hash"] = np.zeros(n, dtype=np.uint64) if hashes else None
+            out["not_kmer"] = np.zeros((n + 63) // 64, dtype=np.uint64)
+            ptrs = [_vp(out[key]) if out[key] is not None else None for key in ("lo", "hi", "hash", "not_kmer")]
+        else:
+            ptrs = [C.c_void_p(into[key]) if into.get(key) else None for key in ("lo", "hi", "hash", "not_kmer")]
+        ds = DkStats()
+        self.engine.check(self.engine._lib.dk_reads_kmers(self.engine.handle, self._h, *ptrs, C.byref(ds)))
+        out["stats"] = ds.as_dict()
+        return out
+
     def close(self):
         if self._h:
             if self.engine._h:

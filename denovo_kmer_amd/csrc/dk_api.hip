@@ -590,6 +590,76 @@ dk_status dk_reads_download(const dk_reads *r, uint64_t *bases, uint64_t *mask)
     return DK_OK;
 }
 
+// device pointer as is; host pointer -> pool buffer that is copied back by finish()
+struct OutBuf {
+    uint64_t *user = nullptr, *dev = nullptr;
+    bool staged = false;
+};
+
+static dk_status out_prepare(dk_engine *e, uint64_t *user, size_t bytes, OutBuf *b)
+{
+    b->user = user;
+    if (!user || bytes == 0) return DK_OK;
+    hipPointerAttribute_t attr;
+    const hipError_t h = hipPointerGetAttributes(&attr, user);
+    if (h == hipSuccess && attr.type == hipMemoryTypeDevice) {
+        b->dev = user;
+        return DK_OK;
+    }
+    (void)hipGetLastError();                    // plain host memory is reported as an error: not one
+    b->staged = true;
+    return pool_alloc(e, bytes, (void **)&b->dev);
+}
+
+dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, uint64_t *kmers_hi, uint64_t *hashes,
+                         uint64_t *not_kmer, dk_stats *stats)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, r != nullptr && r->e == e);
+    const bool wide = e->cfg.k > 32;
+    CHECK_ARG(e, r->n_bases == 0 || kmers_lo != nullptr);
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
+    stage_begin(e);
+    const size_t nb = r->n_bases * 8, nm = (r->n_bases + 63) / 64 * 8;
+    OutBuf lo, hi, hs, nk;
+    dk_status st = out_prepare(e, kmers_lo, nb, &lo);
+    if (st == DK_OK && wide) st = out_prepare(e, kmers_hi, nb, &hi);
+    if (st == DK_OK) st = out_prepare(e, hashes, nb, &hs);
+    if (st == DK_OK) st = out_prepare(e, not_kmer, nm, &nk);
+    hipError_t h = hipSuccess;
+    if (st == DK_OK && r->n_bases) {
+        const StreamView sv = view_of(r);
+        const int grid = grid_for(e, r->n_bases, DIRECT_BLOCK);
+        if (wide)
+            kmers_kernel<true><<<grid, DIRECT_BLOCK, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed,
+                                                                      lo.dev, hi.dev, hs.dev, nk.dev, e->d_ctr);
+        else
+            kmers_kernel<false><<<grid, DIRECT_BLOCK, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed,
+                                                                       lo.dev, nullptr, hs.dev, nk.dev, e->d_ctr);
+        h = hipGetLastError();
+        if (h == hipSuccess) stage_mark(e, "kmers");
+        const OutBuf *bufs[4] = {&lo, &hi, &hs, &nk};
+        const size_t sizes[4] = {nb, nb, nb, nm};
+        for (int i = 0; i < 4 && h == hipSuccess; i++)
+            if (bufs[i]->staged) h = hipMemcpyAsync(bufs[i]->user, bufs[i]->dev, sizes[i], hipMemcpyDeviceToHost, e->stream);
+    }
+    if (st == DK_OK && h == hipSuccess) st = read_counters(e);
+    if (st == DK_OK && h == hipSuccess) st = stage_end(e);
+    for (OutBuf *b : {&lo, &hi, &hs, &nk})
+        if (b->staged) pool_free(e, b->dev);
+    if (st != DK_OK) return st;
+    if (h != hipSuccess) return fail(e, DK_ERR_HIP, "dk_reads_kmers failed: %s", hipGetErrorString(h));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = r->n_reads;
+        stats->n_bases = r->n_bases;
+        stats->n_windows = r->n_windows;
+        stats->n_valid = e->h_ctr->n_valid;
+    }
+    return DK_OK;
+}
+
 void dk_reads_destroy(dk_reads *r)
 {
     if (!r) return;

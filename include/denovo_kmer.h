@@ -139,6 +139,14 @@ dk_status dk_reads_synth(dk_engine *e, const dk_synth_config *cfg, int32_t sampl
 dk_status dk_reads_stats(const dk_reads *r, dk_stats *out);    /* n_reads, n_bases, n_windows */
 /* copy the packed words back (bases: ceil(n_bases/32) words, mask: ceil(n_bases/64) words) */
 dk_status dk_reads_download(const dk_reads *r, uint64_t *bases, uint64_t *mask);
+/* kmer.rs stand-in (extraction / canonicalisation / hashing as an operation of its own): for every
+ * position p of the packed stream (read i starts at offsets[i] + i) the canonical k-mer starting
+ * there -- kmers_lo[p], kmers_hi[p] (k > 32), hashes[p] -- and bit p of not_kmer (MSB-first words like
+ * the batch's mask) = 1 where no k-mer starts (a non-ACGT base in the window, the window runs past
+ * the read, separator); those positions get zeros.  n_bases entries per array, ceil(n_bases/64) mask
+ * words.  Each pointer may be host or device memory; kmers_hi, hashes and not_kmer may be NULL. */
+dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, uint64_t *kmers_hi,
+                         uint64_t *hashes, uint64_t *not_kmer, dk_stats *stats);
 void      dk_reads_destroy(dk_reads *r);
 /* host-side packer (no GPU): returns n_bases; bases/mask sized as for dk_reads_download */
 uint64_t  dk_pack_ascii_host(const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,

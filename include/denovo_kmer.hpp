@@ -91,6 +91,24 @@ public:
         check(dk_reads_from_ascii(e.get(), seq, offsets, n_reads, &r_), e.get());
     }
     ~ReadBatch() { dk_reads_destroy(r_); }
+    // kmer.rs stand-in: canonical k-mer (and hash) of every stream position; not_kmer bit p (MSB first) = no k-mer at p
+    struct Kmers {
+        std::vector<uint64_t> lo, hi, hash, not_kmer;
+        dk_stats stats{};
+    };
+    Kmers kmers(bool with_hashes = true) const
+    {
+        Kmers out;
+        dk_stats st{};
+        check(dk_reads_stats(r_, &st), e_.get());
+        out.lo.resize(st.n_bases);
+        if (e_.k() > 32) out.hi.resize(st.n_bases);
+        if (with_hashes) out.hash.resize(st.n_bases);
+        out.not_kmer.resize((st.n_bases + 63) / 64);
+        check(dk_reads_kmers(e_.get(), r_, out.lo.data(), out.hi.empty() ? nullptr : out.hi.data(),
+                             out.hash.empty() ? nullptr : out.hash.data(), out.not_kmer.data(), &out.stats), e_.get());
+        return out;
+    }
     ReadBatch(const ReadBatch &) = delete;
     ReadBatch &operator=(const ReadBatch &) = delete;
     dk_reads *get() const { return r_; }

@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_runtime_first():
+    """PyTorch's wheel carries its own HIP runtime; in a process shared with the engine it has to come
+    up first, or torch.cuda.is_available() stays false for the tests that hand torch tensors to the
+    engine.  No-op without a GPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield
+
+
 def random_reads(rng, n_reads, min_len, max_len, n_rate=0.0, lower_rate=0.0):
     """ragged random reads over ACGT with optional N / lowercase"""
     reads = []

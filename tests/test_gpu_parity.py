@@ -646,3 +646,56 @@ def test_scan_part_tile_shapes_agree_with_the_oracle(scan_variant, repart_varian
     script = _VARIANT_SCRIPT.format(root=ROOT, tests=os.path.dirname(__file__))
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+
+
+# ---- kmer.rs stand-in: per-position canonical k-mers and hashes (dk_reads_kmers) -----------------------
+
+def _expected_kmers(reads, k, canonical, seed):
+    n_bases = sum(len(r) for r in reads) + len(reads)
+    lo = np.zeros(n_bases, dtype=np.uint64)
+    hi = np.zeros(n_bases, dtype=np.uint64)
+    hs = np.zeros(n_bases, dtype=np.uint64)
+    notk = np.ones(n_bases, dtype=bool)
+    p0 = 0
+    for r in reads:
+        km, valid = orc.read_kmers(r, k, canonical)
+        for j in np.flatnonzero(valid):
+            lo[p0 + j], hi[p0 + j] = km["lo"][j], km["hi"][j]
+            hs[p0 + j] = orc.hash_kmer(int(km["hi"][j]), int(km["lo"][j]), k, seed)
+            notk[p0 + j] = False
+        p0 += len(r) + 1
+    pad = (-n_bases) % 64
+    bits = np.concatenate([notk, np.ones(pad, dtype=bool)]).astype(np.uint8)
+    words = np.packbits(bits).view(">u8").astype(np.uint64)      # MSB-first 64-bit words
+    return lo, hi, hs, words, int((~notk).sum())
+
+
+@pytest.mark.parametrize("k,canonical", [(21, True), (31, True), (32, False), (1, True), (33, True), (51, True), (64, False)])
+def test_per_position_kmers_match_the_oracle(rng, k, canonical):
+    d = dk()
+    import torch
+    torch.cuda.init()            # torch's HIP runtime must come up before the engine's in a shared process
+    reads = random_reads(rng, 60, 0, 180, n_rate=0.02, lower_rate=0.2) + ["", "N", "ACGT" * 20, "acgtn" * 15]
+    seed = 0xC0FFEE12345
+    lo, hi, hs, words, n_valid = _expected_kmers(reads, k, canonical, seed)
+    with d.Engine(k=k, canonical=canonical, seed=seed) as eng:
+        b = d.ReadBatch.from_sequences(eng, reads)
+        out = b.kmers(hashes=True)
+        assert np.array_equal(out["lo"], lo) and np.array_equal(out["hash"], hs)
+        if k > 32:
+            assert np.array_equal(out["hi"], hi)
+        assert np.array_equal(out["not_kmer"], words)
+        assert out["stats"]["n_valid"] == n_valid and out["stats"]["n_windows"] == b.stats()["n_windows"]
+        # device pointers are written in place (here: a torch tensor), optional outputs may be left out
+        n = len(lo)
+        t_lo = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+        t_hi = torch.zeros(n, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        st = b.kmers(into={"lo": t_lo.data_ptr(), "hi": t_hi.data_ptr() if k > 32 else 0})["stats"]
+        assert st["n_valid"] == n_valid
+        assert np.array_equal(t_lo.cpu().numpy().view(np.uint64), lo)
+        if k > 32:
+            assert np.array_equal(t_hi.cpu().numpy().view(np.uint64), hi)
+        # empty batch
+        e = d.ReadBatch.from_sequences(eng, [])
+        assert len(e.kmers()["lo"]) == 0
