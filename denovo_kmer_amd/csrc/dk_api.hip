@@ -630,13 +630,17 @@ dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, ui
     hipError_t h = hipSuccess;
     if (st == DK_OK && r->n_bases) {
         const StreamView sv = view_of(r);
-        const int grid = grid_for(e, r->n_bases, DIRECT_BLOCK);
+        constexpr int KT = 256;                                  // 4 waves, 35 KiB of LDS: four workgroups per CU
+        const uint64_t tile = (uint64_t)KT * (wide ? 8 : 16);
+        const uint64_t n_tiles = (r->n_bases + tile - 1) / tile;
+        if (n_tiles > 0xFFFFFFFFULL) return fail(e, DK_ERR_UNSUPPORTED, "batch too large for dk_reads_kmers");
+        const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * 4);
         if (wide)
-            kmers_kernel<true><<<grid, DIRECT_BLOCK, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed,
-                                                                      lo.dev, hi.dev, hs.dev, nk.dev, e->d_ctr);
+            kmers_tile_kernel<KT, true><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
+                                                                    hi.dev, hs.dev, nk.dev, (uint32_t)n_tiles, e->d_ctr);
         else
-            kmers_kernel<false><<<grid, DIRECT_BLOCK, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed,
-                                                                       lo.dev, nullptr, hs.dev, nk.dev, e->d_ctr);
+            kmers_tile_kernel<KT, false><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
+                                                                     nullptr, hs.dev, nk.dev, (uint32_t)n_tiles, e->d_ctr);
         h = hipGetLastError();
         if (h == hipSuccess) stage_mark(e, "kmers");
         const OutBuf *bufs[4] = {&lo, &hi, &hs, &nk};

@@ -383,6 +383,124 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
 }
 
+// ---- kmer.rs stand-in at streaming speed: canonical k-mer / hash / not-a-k-mer bit per position ------------
+// Same window machinery as scan_part (a thread owns 16 consecutive positions, two or three register
+// words cover all its windows, the reverse complement rolls), but nothing is partitioned: every wave
+// transposes its 1024 results through its own 8.5 KiB of LDS so that each store instruction writes 64
+// consecutive positions.  No workgroup barrier anywhere.
+template <int THREADS, bool WIDE>
+__global__ void __launch_bounds__(THREADS)
+kmers_tile_kernel(StreamView s, int k, int canonical, uint64_t seed, uint64_t *__restrict__ out_lo,
+                  uint64_t *__restrict__ out_hi, uint64_t *__restrict__ out_hash, uint64_t *__restrict__ out_not,
+                  uint32_t n_tiles, Counters *ctr)
+{
+    constexpr int PER_THREAD = WIDE ? 8 : 16;
+    constexpr int TILE = THREADS * PER_THREAD, WAVE_POS = 64 * PER_THREAD, PITCH = PER_THREAD + 1;
+    __shared__ uint64_t xp[THREADS / 64][64 * PITCH];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint64_t *X = xp[wv];
+    const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
+    const int sk = (WIDE ? 128 : 64) - 2 * k;
+    const uint64_t kmask_shift = 64 - k;
+    uint64_t n_valid = 0;
+#pragma unroll 1
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
+        const uint64_t bw = p0 >> 5, mw = p0 >> 6;
+        const uint64_t w0 = s.bases[bw < last_b ? bw : last_b];
+        const uint64_t w1 = s.bases[bw + 1 < last_b ? bw + 1 : last_b];
+        const uint64_t w2 = WIDE ? s.bases[bw + 2 < last_b ? bw + 2 : last_b] : 0;
+        const uint64_t m0 = s.mask[mw < last_m ? mw : last_m];
+        const uint64_t m1 = s.mask[mw + 1 < last_m ? mw + 1 : last_m];
+        const int o = 2 * (int)(p0 & 31);
+        const uint64_t v0 = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
+        const uint64_t v1 = o ? (w1 << o) | (WIDE ? w2 >> (64 - o) : 0) : w1;
+        const uint64_t v2 = WIDE ? (o ? w2 << o : w2) : 0;
+        const int ms = (int)(p0 & 63);
+        const uint64_t mh = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
+        const uint64_t ml = WIDE ? (ms ? m1 << ms : m1) : 0;
+        uint64_t klo[PER_THREAD], khi[WIDE ? PER_THREAD : 1];
+        uint32_t notbits = 0;                                // bit (PER_THREAD - 1 - j): no k-mer at p0 + j
+        uint64_t rch = 0, rcl = 0;
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; j++) {
+            uint64_t kh = 0, kl;
+            bool bad;
+            if (!WIDE) {
+                const uint64_t win = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+                const uint64_t fwd = win >> sk;
+                if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
+                else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
+                bad = ((mh << j) >> kmask_shift) != 0;
+                kl = (canonical && rcl < fwd) ? rcl : fwd;
+            } else {
+                const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+                const uint64_t B = j ? (v1 << (2 * j)) | (v2 >> (64 - 2 * j)) : v1;
+                const uint64_t fh = sk ? A >> sk : A;
+                const uint64_t fl = sk ? (B >> sk) | (A << (64 - sk)) : B;
+                if (j == 0) {
+                    const uint64_t th = ~rev_pairs64(fl), tl = ~rev_pairs64(fh);
+                    rch = sk ? th >> sk : th;
+                    rcl = sk ? (tl >> sk) | (th << (64 - sk)) : tl;
+                } else {
+                    rcl = (rcl >> 2) | (rch << 62);
+                    rch = (rch >> 2) | ((uint64_t)(3u - (uint32_t)(fl & 3)) << (2 * k - 2 - 64));
+                }
+                const uint64_t mx = j ? (mh << j) | (ml >> (64 - j)) : mh;
+                bad = (mx >> kmask_shift) != 0;
+                const bool use_rc = canonical && (rch < fh || (rch == fh && rcl < fl));
+                kh = use_rc ? rch : fh;
+                kl = use_rc ? rcl : fl;
+            }
+            const bool valid = !bad && p0 + j < s.n_bases;
+            klo[j] = valid ? kl : 0;
+            if constexpr (WIDE) khi[j] = valid ? kh : 0;
+            notbits |= (valid ? 0u : 1u) << (PER_THREAD - 1 - j);
+            n_valid += valid;
+        }
+        // the wave's positions [wave0, wave0 + WAVE_POS): store instruction i writes positions wave0 + 64 i + lane
+        const uint64_t wave0 = (uint64_t)tile * TILE + (uint64_t)wv * WAVE_POS;
+        auto emit = [&](const uint64_t (&vals)[PER_THREAD], uint64_t *__restrict__ dst) {
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; j++) X[lane * PITCH + j] = vals[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < PER_THREAD; i++) {
+                const int e = i * 64 + lane;
+                const uint64_t v = X[(e / PER_THREAD) * PITCH + (e % PER_THREAD)];
+                const uint64_t p = wave0 + (uint64_t)e;
+                if (p < s.n_bases) dst[p] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        emit(klo, out_lo);
+        if constexpr (WIDE) {
+            if (out_hi) emit(khi, out_hi);
+        }
+        if (out_hash) {
+            uint64_t hs[PER_THREAD];
+#pragma unroll
+            for (int j = 0; j < PER_THREAD; j++) {
+                const bool valid = !((notbits >> (PER_THREAD - 1 - j)) & 1u);
+                hs[j] = valid ? fmix64(klo[j] ^ hash_tweak<WIDE>(WIDE ? khi[j] : 0, seed)) : 0;
+            }
+            emit(hs, out_hash);
+        }
+        if (out_not) {
+            // 64 / PER_THREAD lanes make one mask word (MSB first)
+            constexpr int LPW = 64 / PER_THREAD;
+            uint64_t word = (uint64_t)notbits << (64 - PER_THREAD * (1 + (lane % LPW)));
+#pragma unroll
+            for (int d = 1; d < LPW; d <<= 1) word |= (uint64_t)__shfl_xor((unsigned long long)word, d);
+            const uint64_t pw = wave0 + (uint64_t)(lane / LPW) * 64;
+            if ((lane % LPW) == 0 && pw < ((s.n_bases + 63) & ~63ULL)) out_not[pw >> 6] = word;
+        }
+    }
+    n_valid = wave_sum(n_valid);
+    if (lane == 0 && n_valid) atomicAdd(&ctr->n_valid, (unsigned long long)n_valid);
+}
+
 // ---- level 2: one workgroup per tile of a level-1 piece; records go to per-SEGMENT regions through
 // global cursors.  Shared write frontiers keep the DRAM pages and L2 lines being written few and
 // hot (every resident workgroup appends to the same 2^b2 segments of one coarse bin at a time),

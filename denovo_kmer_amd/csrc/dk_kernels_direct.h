@@ -455,36 +455,6 @@ popcount_kernel(const uint64_t *__restrict__ words, uint64_t n_words, unsigned l
     if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
 }
 
-// ---- kmer.rs stand-in: canonical k-mer (+ hash) of every stream position --------------------------
-// One thread per position, so every output array is written fully coalesced; a wave covers 64
-// consecutive positions = one word of the not-a-k-mer mask (MSB first, like the batch's own mask).
-template <bool WIDE>
-__global__ void __launch_bounds__(DIRECT_BLOCK)
-kmers_kernel(StreamView s, int k, int canonical, uint64_t seed, uint64_t *__restrict__ out_lo, uint64_t *__restrict__ out_hi,
-             uint64_t *__restrict__ out_hash, uint64_t *__restrict__ out_not, Counters *ctr)
-{
-    const GlobalWords W{s.bases, s.n_bwords - 1}, M{s.mask, s.n_mwords - 1};
-    uint64_t n_valid = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;                   // a multiple of 64
-    const uint64_t n_round = (s.n_bases + 63) & ~63ULL;                         // whole waves stay in the loop
-    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_round; p += stride) {
-        Kmer km{0, 0};
-        bool valid = false;
-        if (p < s.n_bases) valid = extract_kmer<WIDE>(p, k, canonical, W, M, km);
-        if (!valid) km = Kmer{0, 0};
-        n_valid += valid;
-        if (p < s.n_bases) {
-            out_lo[p] = km.lo;
-            if (WIDE && out_hi) out_hi[p] = km.hi;
-            if (out_hash) out_hash[p] = valid ? hash_kmer<WIDE>(km, seed) : 0;
-        }
-        const uint64_t bal = __ballot(!valid);
-        if (out_not && lane_id() == 0) out_not[p >> 6] = __brevll(bal);         // lane l <-> bit 63 - l
-    }
-    n_valid = wave_sum(n_valid);
-    if (lane_id() == 0 && n_valid) atomicAdd(&ctr->n_valid, (unsigned long long)n_valid);
-}
-
 // ---- exact set utilities --------------------------------------------------------------------------
 // every slot of every segment <- EMPTY of its segment (k > 32: high word 0); one thread per 16 bytes
 template <bool WIDE>
