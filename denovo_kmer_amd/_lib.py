@@ -107,6 +107,7 @@ SYMBOLS = {
     "dk_result_copy": (C.c_int32, [_P, _P, _P, _P]),
     "dk_result_device_view": (C.c_int32, [_P, _PP, _PP, _PP, _PU64]),
     "dk_result_merge": (C.c_int32, [_P, _PP, C.c_uint32, C.c_uint32, _PP, C.POINTER(DkStats)]),
+    "dk_result_attach": (C.c_int32, [_P, _P, _P, _P, _U64, _PP]),
     "dk_result_destroy": (None, [_P]),
 }
 

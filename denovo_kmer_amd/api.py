@@ -242,6 +242,7 @@ class KmerCounts:
         self._h = handle
         self.stats = stats
         self._host = None
+        self._keep = None
 
     def __len__(self):
         n = C.c_uint64()
@@ -263,6 +264,21 @@ class KmerCounts:
             order = np.lexsort((lo, hi))
             return hi[order], lo[order], cnt[order]
         return hi, lo, cnt
+
+    @classmethod
+    def from_device(cls, engine, lo_ptr, hi_ptr, cnt_ptr, n, keepalive=None):
+        """wrap caller-owned device arrays (e.g. slices of gathered torch tensors) as a table (dk_result_attach)"""
+        h = C.c_void_p()
+        engine.check(engine._lib.dk_result_attach(engine.handle, C.c_void_p(lo_ptr), C.c_void_p(hi_ptr) if hi_ptr else None,
+                                                  C.c_void_p(cnt_ptr), n, C.byref(h)))
+        t = cls(engine, h, {})
+        t._keep = keepalive
+        return t
+
+    def copy_to_device(self, lo_ptr, hi_ptr, cnt_ptr):
+        """dense copy of the table into caller-owned device (or host) memory: len(self) entries per array"""
+        self.engine.check(self.engine._lib.dk_result_copy(self._h, C.c_void_p(lo_ptr), C.c_void_p(hi_ptr) if hi_ptr else None,
+                                                          C.c_void_p(cnt_ptr)))
 
     def device_view(self):
         plo, phi, pc, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()

@@ -590,6 +590,14 @@ dk_status dk_reads_download(const dk_reads *r, uint64_t *bases, uint64_t *mask)
     return DK_OK;
 }
 
+static bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t attr;
+    const hipError_t h = hipPointerGetAttributes(&attr, p);
+    if (h != hipSuccess) (void)hipGetLastError();          // plain host memory is reported as an error: not one
+    return h == hipSuccess && attr.type == hipMemoryTypeDevice;
+}
+
 // device pointer as is; host pointer -> pool buffer that is copied back by finish()
 struct OutBuf {
     uint64_t *user = nullptr, *dev = nullptr;
@@ -1050,6 +1058,7 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
     res->region_cap = 0;
     memset(res->region_n, 0, sizeof res->region_n);
     res->wide = e->cfg.k > 32;
+    res->owns = true;
     hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
     if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
     memset(e->h_ctr, 0, sizeof(Counters));
@@ -1116,13 +1125,17 @@ dk_status dk_result_copy(const dk_result *res, uint64_t *kmers_lo, uint64_t *kme
     for (uint32_t r = 0; r < res->n_regions; r++) {          // stitch the regions into dense host arrays
         const uint64_t cnt = res->region_n[r], src = (uint64_t)r * res->region_cap;
         if (!cnt) continue;
-        DK_HIP(e, hipMemcpyAsync(kmers_lo + done, res->d_lo + src, cnt * 8, hipMemcpyDeviceToHost, e->stream));
+        // hipMemcpyDefault: the destinations may be host or device memory
+        DK_HIP(e, hipMemcpyAsync(kmers_lo + done, res->d_lo + src, cnt * 8, hipMemcpyDefault, e->stream));
         if (kmers_hi && res->wide)
-            DK_HIP(e, hipMemcpyAsync(kmers_hi + done, res->d_hi + src, cnt * 8, hipMemcpyDeviceToHost, e->stream));
-        DK_HIP(e, hipMemcpyAsync(counts + done, res->d_cnt + src, cnt * 4, hipMemcpyDeviceToHost, e->stream));
+            DK_HIP(e, hipMemcpyAsync(kmers_hi + done, res->d_hi + src, cnt * 8, hipMemcpyDefault, e->stream));
+        DK_HIP(e, hipMemcpyAsync(counts + done, res->d_cnt + src, cnt * 4, hipMemcpyDefault, e->stream));
         done += cnt;
     }
-    if (kmers_hi && !res->wide) memset(kmers_hi, 0, res->n * 8);
+    if (kmers_hi && !res->wide) {
+        if (is_device_ptr(kmers_hi)) DK_HIP(e, hipMemsetAsync(kmers_hi, 0, res->n * 8, e->stream));
+        else memset(kmers_hi, 0, res->n * 8);
+    }
     DK_HIP(e, hipStreamSynchronize(e->stream));
     return DK_OK;
 }
@@ -1196,6 +1209,7 @@ dk_status dk_result_merge(dk_engine *e, const dk_result *const *results, uint32_
     res->region_cap = 0;
     memset(res->region_n, 0, sizeof res->region_n);
     res->wide = wide;
+    res->owns = true;
     hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
     if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
     memset(e->h_ctr, 0, sizeof(Counters));
@@ -1213,12 +1227,39 @@ dk_status dk_result_merge(dk_engine *e, const dk_result *const *results, uint32_
     return DK_OK;
 }
 
+dk_status dk_result_attach(dk_engine *e, const void *d_kmers_lo, const void *d_kmers_hi, const void *d_counts, uint64_t n,
+                           dk_result **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    *out = nullptr;
+    const bool wide = e->cfg.k > 32;
+    CHECK_ARG(e, n == 0 || (d_kmers_lo && d_counts && (d_kmers_hi || !wide)));
+    dk_result *res = new (std::nothrow) dk_result();
+    if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
+    res->e = e;
+    res->d_lo = (uint64_t *)d_kmers_lo;
+    res->d_hi = wide ? (uint64_t *)d_kmers_hi : nullptr;
+    res->d_cnt = (uint32_t *)d_counts;
+    res->n = n;
+    res->wide = wide;
+    res->owns = false;
+    res->n_regions = 1;
+    res->region_cap = n;
+    memset(res->region_n, 0, sizeof res->region_n);
+    res->region_n[0] = n;
+    *out = res;
+    return DK_OK;
+}
+
 void dk_result_destroy(dk_result *res)
 {
     if (!res) return;
-    pool_free(res->e, res->d_lo);
-    pool_free(res->e, res->d_hi);
-    pool_free(res->e, res->d_cnt);
+    if (res->owns) {
+        pool_free(res->e, res->d_lo);
+        pool_free(res->e, res->d_hi);
+        pool_free(res->e, res->d_cnt);
+    }
     delete res;
 }
 

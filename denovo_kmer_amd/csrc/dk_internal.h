@@ -53,6 +53,7 @@ struct dk_result {
     uint32_t *d_cnt;
     uint64_t n;
     bool wide;
+    bool owns;                    // false: the arrays belong to the caller (dk_result_attach)
     // Region r of the arrays holds region_n[r] entries starting at r * region_cap.  The direct
     // family writes one dense region; the bucketed count kernel appends through RESULT_REGIONS
     // independent fill counters (one global counter saturates near 10^8 atomics/s) and the regions

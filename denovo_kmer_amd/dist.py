@@ -108,3 +108,50 @@ def merge_counts(hi, lo, cnt, min_count=1, group=None):
     sums = np.add.reduceat(acnt, idx)
     keep = sums >= min_count
     return ahi[idx][keep], alo[idx][keep], np.minimum(sums[keep], 0xFFFFFFFF).astype(np.uint32)
+
+
+def merge_counts_device(engine, table, min_count=1, group=None, stage_through_cpu=False):
+    """Device-side counterpart of merge_counts for tables too large to pickle: every rank's (k-mer, count)
+    arrays are gathered with all_gather_into_tensor (padded to the largest table), attached as tables in
+    place (dk_result_attach) and summed by k-mer with dk_result_merge.  Returns the merged KmerCounts
+    (identical on every rank).  `table` must come from an engine with min_count=1.
+    stage_through_cpu: gloo rehearsal (no device collectives)."""
+    from .api import KmerCounter, KmerCounts
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", engine.device_id)
+    wide = engine.k > 32
+    n = len(table)
+    sizes = torch.zeros(world, dtype=torch.int64, device="cpu" if stage_through_cpu else dev)
+    sizes[dist.get_rank(group)] = n
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+    sizes = [int(x) for x in sizes.cpu()]
+    cap = max(max(sizes), 1)
+    lo = torch.zeros(cap, dtype=torch.int64, device=dev)
+    hi = torch.zeros(cap if wide else 1, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(cap, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    if n:
+        table.copy_to_device(lo.data_ptr(), hi.data_ptr() if wide else 0, cnt.data_ptr())
+    parts = []
+    for t in ([lo, cnt, hi] if wide else [lo, cnt]):
+        if stage_through_cpu:
+            g = torch.empty(world * cap, dtype=t.dtype)
+            dist.all_gather_into_tensor(g, t.cpu(), group=group)
+            g = g.to(dev)
+        else:
+            g = torch.empty(world * cap, dtype=t.dtype, device=dev)
+            dist.all_gather_into_tensor(g, t, group=group)
+        parts.append(g)
+    torch.cuda.synchronize()
+    glo, gcnt = parts[0], parts[1]
+    ghi = parts[2] if wide else None
+    tables = []
+    for r in range(world):
+        if sizes[r] == 0:
+            continue
+        tables.append(KmerCounts.from_device(engine, glo[r * cap:].data_ptr(), ghi[r * cap:].data_ptr() if wide else 0,
+                                             gcnt[r * cap:].data_ptr(), sizes[r], keepalive=(glo, ghi, gcnt)))
+    merged = KmerCounter(engine).merge(tables, min_count=min_count)
+    for t in tables:
+        t.close()
+    return merged

@@ -186,8 +186,12 @@ void      dk_set_destroy(dk_set *s);
  * of the batch (KmerCounter semantics). */
 dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, dk_stats *stats);
 dk_status dk_result_size(const dk_result *res, uint64_t *n);
-/* unordered copy to host; kmers_hi may be NULL when k <= 32 */
+/* unordered dense copy; the destinations may be host or device memory; kmers_hi may be NULL when k <= 32 */
 dk_status dk_result_copy(const dk_result *res, uint64_t *kmers_lo, uint64_t *kmers_hi, uint32_t *counts);
+/* wrap caller-owned device arrays of n (k-mer, count) entries as a table (borrowed, not freed): the
+ * receiving side of a multi-GPU merge -- gather the ranks' tables with RCCL, attach, dk_result_merge */
+dk_status dk_result_attach(dk_engine *e, const void *d_kmers_lo, const void *d_kmers_hi /* NULL if k<=32 */,
+                           const void *d_counts, uint64_t n, dk_result **out);
 dk_status dk_result_device_view(const dk_result *res, const void **d_kmers_lo, const void **d_kmers_hi,
                                 const void **d_counts, uint64_t *n);
 /* Sum n_results tables by k-mer (a child processed in several batches, or the per-GPU tables of a

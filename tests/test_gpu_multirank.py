@@ -25,7 +25,7 @@ def _worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, set_kind, 
     import torch.distributed as dist
 
     import denovo_kmer_amd as dk
-    from denovo_kmer_amd.dist import local_reduce_fn, merge_counts, or_allreduce_, shard_range
+    from denovo_kmer_amd.dist import local_reduce_fn, merge_counts, merge_counts_device, or_allreduce_, shard_range
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -45,6 +45,14 @@ def _worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, set_kind, 
         res = dk.KmerCounter(eng).child_only(dk.ReadBatch.synth(eng, gcfg, 2, lo, hi - lo), ks)
         khi, klo, kcnt = res.to_host()
         mhi, mlo, mcnt = merge_counts(khi, klo, kcnt, min_count=1)
+        # the device-side merge (gathered tensors attached as tables, summed on the GPU) must agree with it
+        dm = merge_counts_device(eng, res, min_count=1, stage_through_cpu=True)
+        dhi, dlo, dcnt = dm.to_host(sort=True)
+        assert np.array_equal(dhi, mhi) and np.array_equal(dlo, mlo) and np.array_equal(dcnt, mcnt)
+        dm2 = merge_counts_device(eng, res, min_count=2, stage_through_cpu=True)
+        keep = mcnt >= 2
+        d2 = dm2.to_host(sort=True)
+        assert np.array_equal(d2[1], mlo[keep]) and np.array_equal(d2[2], mcnt[keep])
         q.put((rank, filt.cpu().numpy().view(np.uint64).copy(), mhi, mlo, mcnt, n_keys))
         eng.close()
     finally:
