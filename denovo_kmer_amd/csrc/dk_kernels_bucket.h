@@ -726,7 +726,9 @@ seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int
 }
 
 // absent records of segment s are written to miss[s * miss_cap ...], their number to miss_cnt[s]
-template <class R>
+// NH > 0: the number of hash bits is a compile-time constant (the four LDS reads of a record are then
+// issued back to back instead of one by one behind the short-circuit test); NH == 0: n_hashes at run time
+template <class R, int NH>
 __global__ void __launch_bounds__(SEG_THREADS)
 seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
                  R *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
@@ -760,9 +762,19 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
             const uint32_t blk = (uint32_t)(hu >> blk_shift) & (SEG_BLOCKS - 1);
             const uint32_t a = (uint32_t)(hu & 511), d = (uint32_t)((hu >> 9) & 511) | 1u;
             bool all = true;
-            for (int j = 0; j < n_hashes; j++) {
-                const uint32_t bit = (a + (uint32_t)j * d) & 511;
-                all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
+            if constexpr (NH > 0) {
+                uint32_t acc = 1u;
+#pragma unroll
+                for (int j = 0; j < NH; j++) {
+                    const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                    acc &= seg[blk * 16 + (bit >> 5)] >> (bit & 31);
+                }
+                all = acc & 1u;
+            } else {
+                for (int j = 0; j < n_hashes; j++) {
+                    const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                    all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
+                }
             }
             const bool absent = have[u] && !all;
             const uint64_t b = __ballot(absent);
@@ -1470,8 +1482,11 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         if (s->exact)
             seg_exact_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
                 s->d_words, list, p.T, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+        else if (e->cfg.n_hashes == 4)
+            seg_probe_kernel<R, 4><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+                s->d_words, list, 4, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         else
-            seg_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
+            seg_probe_kernel<R, 0><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
                 s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
