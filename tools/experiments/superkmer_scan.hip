@@ -162,6 +162,97 @@ superkmer_kernel(const uint64_t *__restrict__ bases, const uint64_t *__restrict_
     if ((threadIdx.x & 63) == 63 && tot_rec) atomicAdd(&counters[0], tot_rec);
 }
 
+// ---- segment-kernel side: expand the k-mers of each record, hash them, test four bits of an LDS-resident filter ----
+__device__ __forceinline__ uint64_t fmix64(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint64_t rev_pairs64(uint64_t x)
+{
+    uint64_t r = __brevll(x);
+    return ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+}
+// k-mer number idx of a record: bases idx .. idx + K - 1 of the 104-bit base string {a[39:0], b}
+__device__ __forceinline__ uint64_t kmer_of(const Rec &r, uint32_t idx)
+{
+    const uint64_t hi = r.a << 24 | r.b >> 40, lo = r.b << 24;                   // bases left-aligned in (hi, lo)
+    const int sh = 2 * (int)idx;
+    const uint64_t v = sh ? (hi << sh) | (lo >> (64 - sh)) : hi;
+    const uint64_t fwd = v >> (64 - 2 * K);
+    const uint64_t rc = (~rev_pairs64(fwd)) >> (64 - 2 * K);
+    return rc < fwd ? rc : fwd;
+}
+__device__ __forceinline__ bool test4(const uint32_t *seg, uint64_t h)
+{
+    const uint32_t blk = (uint32_t)(h >> 39) & 1023u, a = (uint32_t)(h & 511), d = (uint32_t)((h >> 9) & 511) | 1u;
+    uint32_t acc = 1u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t bit = (a + (uint32_t)j * d) & 511;
+        acc &= seg[blk * 16 + (bit >> 5)] >> (bit & 31);
+    }
+    return acc & 1u;
+}
+
+// A: one record per lane, each lane loops over its own k-mers (the wave runs to its longest record)
+__global__ void __launch_bounds__(1024)
+expand_lane_kernel(const Rec *__restrict__ recs, uint64_t n_slots, unsigned long long *counters)
+{
+    __shared__ uint32_t seg[16384];
+    for (int i = threadIdx.x; i < 16384; i += 1024) seg[i] = fmix32(i * 2654435761u + blockIdx.x);
+    __syncthreads();
+    unsigned long long hits = 0, kmers = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * 1024) {
+        const Rec r = recs[i];
+        const uint32_t count = (uint32_t)(r.a >> 40) & 63u;
+        for (uint32_t c = 0; c < count; c++) hits += test4(seg, fmix64(kmer_of(r, c) ^ 20260313ULL));
+        kmers += count;
+    }
+    for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d); kmers += __shfl_down(kmers, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[2], hits); atomicAdd(&counters[3], kmers); }
+}
+
+// B: the k-mers of a wave's 64 records are flattened: lane l takes k-mers l, l + 64, ... of the wave's list
+__global__ void __launch_bounds__(1024)
+expand_flat_kernel(const Rec *__restrict__ recs, uint64_t n_slots, unsigned long long *counters)
+{
+    __shared__ uint32_t seg[16384];
+    __shared__ Rec wrec[16][64];
+    __shared__ uint32_t wpre[16][65];
+    for (int i = threadIdx.x; i < 16384; i += 1024) seg[i] = fmix32(i * 2654435761u + blockIdx.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long hits = 0, kmers = 0;
+    const uint64_t n_round = (n_slots + 63) & ~63ULL;
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n_round; i += (uint64_t)gridDim.x * 1024) {
+        Rec r{0, 0};
+        if (i < n_slots) r = recs[i];
+        const uint32_t count = (uint32_t)(r.a >> 40) & 63u;
+        uint32_t incl = count;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        wrec[wv][lane] = r;
+        wpre[wv][lane + 1] = incl;
+        if (lane == 0) wpre[wv][0] = 0;
+        const uint32_t total = __shfl(incl, 63);
+        for (uint32_t t = lane; t < total; t += 64) {
+            // record of k-mer t: largest q with wpre[q] <= t
+            uint32_t q = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1)
+                if (wpre[wv][q + step] <= t) q += step;
+            const Rec rr = wrec[wv][q];
+            hits += test4(seg, fmix64(kmer_of(rr, t - wpre[wv][q]) ^ 20260313ULL));
+        }
+        kmers += count;
+    }
+    for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d); kmers += __shfl_down(kmers, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counters[2], hits); atomicAdd(&counters[3], kmers); }
+}
+
 int main()
 {
     const uint64_t n_reads = 12800000, L = 150;
@@ -180,7 +271,7 @@ int main()
     hipMalloc(&db, n_words * 8);
     hipMalloc(&dm, hm.size() * 8);
     hipMalloc(&dout, (n_pos / 3 + (1 << 20)) * sizeof(Rec));
-    hipMalloc(&dc, 16);
+    hipMalloc(&dc, 64);
     hipMemcpy(db, hb.data(), n_words * 8, hipMemcpyHostToDevice);
     hipMemcpy(dm, hm.data(), hm.size() * 8, hipMemcpyHostToDevice);
     hipEvent_t a, b;
@@ -191,7 +282,7 @@ int main()
     float best = 1e9f;
     unsigned long long hc[2] = {0, 0};
     for (int it = 0; it < 4; it++) {
-        hipMemset(dc, 0, 16);
+        hipMemset(dc, 0, 64);
         hipEventRecord(a);
         superkmer_kernel<<<grid, 256>>>(db, dm, n_pos, n_words, dout, dc);
         hipEventRecord(b);
@@ -205,6 +296,31 @@ int main()
            (unsigned long long)n_pos, hc[1], hc[0], (double)hc[1] / hc[0], 16.0 * hc[0] / hc[1]);
     printf("scan: %.2f ms = %.1f Gk-mers/s; bytes in %.2f GB + out %.2f GB = %.0f GB/s\n", best, hc[1] / best / 1e6,
            n_pos * 3 / 8 / 1e9, hc[0] * 16 / 1e9, (n_pos * 3 / 8 + hc[0] * 16.0) / best / 1e6);
+    // the output slots are 64 * PT / 3 records per wave tile; unused slots must read as count 0: redo the scan
+    // into a zeroed buffer, then run the two expansion variants over all slots
+    const uint64_t n_slots = ((n_threads + 63) / 64) * (64 * PT / 3);
+    hipMemset(dout, 0, n_slots * sizeof(Rec));
+    hipMemset(dc, 0, 64);
+    superkmer_kernel<<<grid, 256>>>(db, dm, n_pos, n_words, dout, dc);
+    hipDeviceSynchronize();
+    for (int variant = 0; variant < 2; variant++) {
+        float bestx = 1e9f;
+        unsigned long long hx[4] = {0, 0, 0, 0};
+        for (int it = 0; it < 3; it++) {
+            hipMemset(dc, 0, 64);
+            hipEventRecord(a);
+            if (variant == 0) expand_lane_kernel<<<512, 1024>>>(dout, n_slots, dc);
+            else expand_flat_kernel<<<512, 1024>>>(dout, n_slots, dc);
+            hipEventRecord(b);
+            hipEventSynchronize(b);
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            if (ms < bestx) bestx = ms;
+            hipMemcpy(hx, dc, 32, hipMemcpyDeviceToHost);
+        }
+        printf("expand (%s): %.2f ms = %.1f Gk-mers/s, %llu k-mers, %llu filter hits (slots read: %.2f GB)\n",
+               variant == 0 ? "lane per record" : "flattened per wave", bestx, hx[3] / bestx / 1e6, hx[3], hx[2], n_slots * 16 / 1e9);
+    }
     // CPU re-derivation of the counts on the first reads
     const uint64_t chk_reads = 20000;
     uint64_t c_rec = 0, c_km = 0;
