@@ -157,6 +157,7 @@ struct SplitLds {
     uint32_t off[MAX_BINS];     // tile offset of each bin in stage[]
     uint32_t delta[MAX_BINS];   // index in the piece = stage index + delta[bin]  (mod 2^32)
     uint32_t cur[MAX_BINS];     // running fill of this workgroup's piece of each bin
+    unsigned long long gptr[MAX_BINS];   // scan_part: byte address of (piece slot of stage index 0) per bin
     uint32_t total;
     uint32_t ovf_seen;          // some bin of this workgroup has run past its capacity (never cleared)
 };
@@ -229,6 +230,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
 
     // the tile being hashed: stream left-aligned at p0 -- bases in (v0, v1[, v2]), flags in (mh, ml)
     uint64_t p0 = 0, v0 = 0, v1 = 0, v2 = 0, mh = 0, ml = 0, rch = 0, rcl = 0;
+    uint32_t okbits = 0;                                   // k <= 32: bit (PER_THREAD - 1 - j) = window j is a k-mer
     auto prep = [&](uint32_t tile, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t m0, uint64_t m1) {
         p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
         const int o = 2 * (int)(p0 & 31);                 // PER_THREAD 8: 0,16,32,48; 16: 0,32
@@ -238,6 +240,19 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         const int ms = (int)(p0 & 63);
         mh = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
         ml = WIDE ? (ms ? m1 << ms : m1) : 0;
+        if constexpr (!WIDE) {
+            // all PER_THREAD validity flags at once: smear every mask flag over the k - 1 positions before it
+            // (bit 63 - j of y = any flag in [j, j + k)), then cut at the end of the stream
+            uint64_t y = mh;
+            int cov = 1;
+            while (cov * 2 <= k) { y |= y << cov; cov *= 2; }
+            if (cov < k) y |= y << (k - cov);
+            const uint32_t bad = (uint32_t)(y >> (64 - PER_THREAD));
+            const uint64_t left = p0 < s.n_bases ? s.n_bases - p0 : 0;      // positions of this thread inside the stream
+            const uint32_t inside = left >= (uint64_t)PER_THREAD ? (1u << PER_THREAD) - 1u
+                                                                 : ~((1u << (PER_THREAD - (uint32_t)left)) - 1u) & ((1u << PER_THREAD) - 1u);
+            okbits = ~bad & inside;
+        }
     };
     // window j of the tile being hashed -> record; returns true when the window is a k-mer
     auto window = [&](int j, R &rec) -> bool {
@@ -248,7 +263,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             const uint64_t fwd = win >> sk;
             if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
             else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
-            bad = ((mh << j) >> kmask_shift) != 0;
+            bad = false;                                   // decided for all windows at once in prep()
             kl = (canonical && rcl < fwd) ? rcl : fwd;
         } else {
             const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
@@ -271,7 +286,8 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         }
         rec.h = fmix64(kl ^ hash_tweak<WIDE>(kh, seed));
         if constexpr (WIDE) rec.hi = kh;
-        return !bad && p0 + j < s.n_bases;
+        if constexpr (!WIDE) return (okbits >> (PER_THREAD - 1 - j)) & 1u;
+        else return !bad && p0 + j < s.n_bases;
     };
 
     uint32_t tile = blockIdx.x;
@@ -320,6 +336,8 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                 if (tid < nbins) {
                     L.off[tid] = ex;
                     L.delta[tid] = cu - ex;
+                    // where stage slot 0 would land in this bin's piece: the copy-out adds 8 * slot
+                    L.gptr[tid] = (unsigned long long)(uintptr_t)(out + ((uint64_t)tid * bin_stride + piece_base + cu - ex));
                     L.cur[tid] = cu + c;
                     if (cu + c > capw) L.ovf_seen = 1;
                     if (tid == nbins - 1) L.total = ex + c;
@@ -349,10 +367,12 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                 const bool mine = i < total;
                 R rec;
                 uint32_t bin = 0, idx = 0;
+                R *dst = nullptr;
                 if (mine) {
                     rec = L.stage[i];
                     bin = bin_of(rec.h);
-                    idx = i + L.delta[bin];              // 32-bit on purpose: delta is a wrapped difference
+                    if (!checked) dst = (R *)(uintptr_t)L.gptr[bin] + i;
+                    else idx = i + L.delta[bin];         // 32-bit on purpose: delta is a wrapped difference
                 }
                 if (has_next) {
                     uint32_t r = 0;
@@ -363,7 +383,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                     rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
                 }
                 if (!checked) {
-                    if (mine) out[(uint64_t)bin * bin_stride + piece_base + idx] = rec;
+                    if (mine) *dst = rec;
                 } else {
                     if (mine && idx < capw) out[(uint64_t)bin * bin_stride + piece_base + idx] = rec;
                     ovf_append(ovf, mine && idx >= capw, rec, n_overflow);
