@@ -31,6 +31,7 @@ constexpr int PART_PER_THREAD = 8;
 constexpr int PART_TILE = PART_THREADS * PART_PER_THREAD;   // positions (or records) per tile
 constexpr int MAX_BIN_BITS = 9;
 constexpr int MAX_BINS = 1 << MAX_BIN_BITS;
+constexpr int MAX_SEG_BITS = 23;                       // two levels up to 18 bits, three levels beyond (coarse regions <= 2^15: grid y)
 constexpr int CURSOR_STRIDE = 32;                      // level-1 cursors on separate 128-B lines
 
 constexpr int SEG_THREADS = 1024;
@@ -45,7 +46,10 @@ constexpr int MAX_R = 4;                               // level-2 producer group
 // Level-1 cursors live in LDS for the life of the workgroup; piece sizes are stored once at the end.
 struct BucketPlan {
     int T;                 // log2(number of segments)
-    int b1, b2;            // hash bits consumed at level 1 / level 2 (b1 + b2 = T, b2 >= 1)
+    int b1, b2;            // hash bits consumed at level 1 / level 2 (b1 + b2 [+ b3] = T, b2 >= 1)
+    int b3;                // > 0: a third level (2^19 segments and more): level 2 fills 2^(b1+b2) coarse regions of
+                           // capA records, a second repart pass splits each by b3 more bits into the segments
+    uint32_t capA;
     uint32_t p1, p2;       // bins at each level
     uint64_t n_seg;
     uint32_t G;            // scan_part workgroups = level-1 pieces per bin
@@ -1281,13 +1285,13 @@ inline uint32_t piece_capacity(double mean, double ratio)
 }
 
 // scan_part geometry: 2 = 512 threads x 16 positions, two workgroups per CU (default); 6 = 1024 x 16, one
-// per CU, for 2^16 segments and more -- with 256-512 level-1 bins the 8192-record tile leaves 16-32
+// per CU, from 256 level-1 bins (2^16 segments) on -- with 256-512 level-1 bins the 8192-record tile leaves 16-32
 // records per run and half-empty level-1 pieces, which the 16384-record tile and half as many
 // workgroups repair (2^37 bits: 61 -> 76 Gk-mers/s).  DK_SCAN_VARIANT forces one (1, 3, 4, 5: experiments).
-inline int scan_variant(int T)
+inline int scan_variant(int b1)
 {
     static const int forced = [] { const char *e = getenv("DK_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
-    return forced ? forced : T >= 16 ? 6 : 2;
+    return forced ? forced : b1 >= 8 ? 6 : 2;
 }
 
 // KmerCounter (no set): the segments are only counting units, so their number follows the batch, not the
@@ -1306,17 +1310,27 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
 {
     const bool wide = e->cfg.k > 32;
     p->T = T_override > 0 ? T_override : (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
-    if (p->T < 1 || p->T > 2 * MAX_BIN_BITS) return false;
+    if (p->T < 1 || p->T > MAX_SEG_BITS) return false;
     static const int b1_up = [] { const char *v = getenv("DK_B1_UP"); return v ? atoi(v) : 0; }();
-    p->b1 = (p->T + b1_up) / 2;
-    if (p->b1 > MAX_BIN_BITS) p->b1 = MAX_BIN_BITS;
-    if (p->T - p->b1 > MAX_BIN_BITS) p->b1 = p->T - MAX_BIN_BITS;
-    p->b2 = p->T - p->b1;
+    static const int force3 = [] { const char *v = getenv("DK_FORCE_L3"); return v ? atoi(v) : 0; }();
+    p->b3 = 0;
+    p->capA = 0;
+    if (p->T > 2 * MAX_BIN_BITS || (force3 && p->T >= 3)) {
+        // three levels: thirds of T; the coarse regions (b1 + b2 bits) index the grid's y dimension
+        p->b1 = p->T / 3;
+        p->b2 = (p->T - p->b1) / 2;
+        p->b3 = p->T - p->b1 - p->b2;
+    } else {
+        p->b1 = (p->T + b1_up) / 2;
+        if (p->b1 > MAX_BIN_BITS) p->b1 = MAX_BIN_BITS;
+        if (p->T - p->b1 > MAX_BIN_BITS) p->b1 = p->T - MAX_BIN_BITS;
+        p->b2 = p->T - p->b1;
+    }
     p->p1 = 1u << p->b1;
     p->p2 = 1u << p->b2;
     p->n_seg = 1ULL << p->T;
     p->n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
-    const int v = p->variant = scan_variant(p->T);
+    const int v = p->variant = scan_variant(p->b1);
     // 16-byte records (k > 32): 512 threads x 8 positions so that the LDS stage stays at 64 KiB
     p->tile = wide ? 512 * 8 : v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : v == 4 ? 256 * 16 : v == 5 ? 128 * 16 : v == 6 ? 1024 * 16 : 1024 * 8;
     const int blocks_per_cu = wide ? 2 : v == 1 ? 1 : v == 3 ? 4 : v == 4 ? 4 : v == 5 ? 6 : v == 6 ? 1 : 2;
@@ -1332,6 +1346,11 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 cursors
     p->capw = piece_capacity(m1, 4.0);
     p->cap2 = piece_capacity(m2, 64.0);
+    if (p->b3) {
+        const double mA = (double)p->n_max / (double)(1ULL << (p->b1 + p->b2));
+        if (mA * 2 + 1e6 >= 4.0e9) return false;
+        p->capA = piece_capacity(mA, 64.0);
+    }
     // piece stride = an odd multiple of 128 B past a 4-KiB boundary: the workgroups of repart read the same
     // tile of neighbouring pieces at the same time, and strides near a large power of two pile those reads
     // onto few HBM channels (measured 2 % on the whole pass)
@@ -1339,18 +1358,23 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     return true;
 }
 
-// AUTO mode: bucketed when sweeping the filter once costs less than one random 64-B block per k-mer
+// AUTO mode: the bucketed family costs ~9-12 ps per position plus one sweep of the set (~0.24 ps per byte at
+// 4.1-4.8 TB/s), the direct family ~54 ps per position (one random 64-B block per k-mer plus the global count
+// table); measured crossover near 175 bytes of set per position (2^40 bits against a 12.8 M-read batch: 23.6 vs
+// 14.7 Gk-mers/s).  Below a few million positions the fixed launch and sync costs of five kernels decide.
 inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases)
 {
     const uint64_t filter_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
     const int T = (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
-    if (T < 1 || T > 2 * MAX_BIN_BITS) return false;
-    return filter_bytes >= (32ULL << 20) && n_bases * 16 >= filter_bytes;
+    if (T < 1 || T > MAX_SEG_BITS) return false;
+    return filter_bytes >= (32ULL << 20) && n_bases >= (4ULL << 20) && n_bases * 128 >= filter_bytes;
 }
 
 template <class R>
 struct BucketBufs {
-    R *a = nullptr, *b = nullptr;             // level-1 pieces (later: absent lists) / segment regions
+    R *a = nullptr, *b = nullptr;             // level-1 pieces / regions; which one ends up holding the segments' records
+    R *rec = nullptr, *scratch = nullptr;     // depends on the number of levels: rec = final records, scratch = the other (absent lists)
+    uint32_t *cursorA = nullptr;              // three levels: fill of the coarse regions
     uint32_t *cnt = nullptr;                  // cnt1 [p1 * G] | cursor2 [n_seg] | miss_cnt [n_seg]
     uint32_t *cnt1 = nullptr, *cursor2 = nullptr, *miss_cnt = nullptr;
     R *ovf = nullptr;                         // overflow records
@@ -1371,7 +1395,7 @@ inline void free_bufs(dk_engine *e, BucketBufs<R> &B)
     pool_free(e, B.extra_idx);
 }
 
-// scan_part + repart: afterwards B.b / B.cursor2 hold every record of the batch grouped by segment,
+// scan_part + repart (+ repart): afterwards B.rec / B.cursor2 hold every record of the batch grouped by segment,
 // except the records that did not fit, which are in B.ovf (Counters::n_ovf of them)
 template <bool WIDE>
 inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p,
@@ -1380,13 +1404,19 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     using R = typename RecOf<WIDE>::type;
     const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
     const uint64_t lvl1_recs = (uint64_t)p.p1 * p.G * p.capw;
+    const uint64_t n_coarse = p.b3 ? 1ULL << (p.b1 + p.b2) : 0;
+    const uint64_t coarse_recs = n_coarse * p.capA;
     DK_TRY(pool_alloc(e, std::max(seg_recs, lvl1_recs) * sizeof(R), (void **)&B.a));
-    DK_TRY(pool_alloc(e, seg_recs * sizeof(R), (void **)&B.b));
+    DK_TRY(pool_alloc(e, std::max(seg_recs, coarse_recs) * sizeof(R), (void **)&B.b));
     const uint64_t n1 = (uint64_t)p.p1 * p.G;
-    DK_TRY(pool_alloc(e, (n1 + 2 * p.n_seg) * 4, (void **)&B.cnt));
+    DK_TRY(pool_alloc(e, (n1 + 2 * p.n_seg + n_coarse) * 4, (void **)&B.cnt));
     B.cnt1 = B.cnt;
     B.cursor2 = B.cnt + n1;
     B.miss_cnt = B.cursor2 + p.n_seg;
+    B.cursorA = B.miss_cnt + p.n_seg;
+    B.rec = p.b3 ? B.a : B.b;
+    B.scratch = p.b3 ? B.b : B.a;
+    if (n_coarse) DK_HIP(e, hipMemsetAsync(B.cursorA, 0, n_coarse * 4, e->stream));
     B.ovf_cap = std::max<uint64_t>(1ULL << 20, p.n_max / 8);
     DK_TRY(pool_alloc(e, B.ovf_cap * sizeof(R), (void **)&B.ovf));
     DK_HIP(e, hipMemsetAsync(B.cursor2, 0, p.n_seg * 4, e->stream));
@@ -1402,17 +1432,31 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #define DK_SCAN_LAUNCH(TH, PT, W)                                                                                        \
     scan_part_kernel<TH, PT, W, WIDE><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
                                                                  p.b1, p.capw, B.a, B.cnt1, n_tiles, ovf, e->d_ctr)
+    // level 2: the level-1 pieces -> the segments' regions, or (three levels) -> 2^(b1+b2) coarse regions
 #define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
     do {                                                                                                  \
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                          \
-            B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.cap2, B.b, B.cursor2, ovf, e->d_ctr);             \
+            B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                         \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr);                                                  \
+    } while (0)
+    // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
+#define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \
+    do {                                                                                                  \
+        const uint32_t tpp = (p.capA + TH * PT - 1) / (TH * PT);                                           \
+        repart_kernel<TH, PT, W, R><<<dim3(tpp, 1u << (p.b1 + p.b2)), TH, 0, e->stream>>>(                 \
+            B.b, B.cursorA, 1u, p.capA, tpp, p.b1 + p.b2, p.b3, p.cap2, B.a, B.cursor2, ovf, e->d_ctr);    \
     } while (0)
     if constexpr (WIDE) {
         DK_SCAN_LAUNCH(512, 8, 4);
         DK_HIP(e, hipGetLastError());
         stage_mark(e, "scan_part");
         DK_REPART_LAUNCH(512, 8, 8);
+        if (p.b3) {
+            DK_HIP(e, hipGetLastError());
+            stage_mark(e, "repart");
+            DK_REPART3_LAUNCH(512, 8, 8);
+        }
     } else {
         switch (p.variant) {
         case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
@@ -1428,11 +1472,17 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
         static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
         if (rv == 1) DK_REPART_LAUNCH(1024, 16, 4);
         else DK_REPART_LAUNCH(1024, 8, 8);
+        if (p.b3) {
+            DK_HIP(e, hipGetLastError());
+            stage_mark(e, "repart");
+            DK_REPART3_LAUNCH(1024, 8, 8);
+        }
     }
 #undef DK_SCAN_LAUNCH
 #undef DK_REPART_LAUNCH
+#undef DK_REPART3_LAUNCH
     DK_HIP(e, hipGetLastError());
-    stage_mark(e, "repart");
+    stage_mark(e, p.b3 ? "repart3" : "repart");
     return DK_OK;
 }
 
@@ -1457,7 +1507,7 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B);
     if (st == DK_OK) {
-        const PieceList<R> pl{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
+        const PieceList<R> pl{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
         if (s->exact)
             seg_exact_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, p.T, e->d_ctr);
         else
@@ -1496,22 +1546,22 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B);
-    PieceList<R> list{B.b, B.cursor2, 1, p.cap2, nullptr, nullptr};
+    PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
         if (s->exact)
             seg_exact_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, p.T, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+                s->d_words, list, p.T, B.scratch, miss_cap, B.miss_cnt, e->d_ctr);
         else if (e->cfg.n_hashes == 4)
             seg_probe_kernel<R, 4><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, 4, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+                s->d_words, list, 4, 64 - p.T - SEG_LOG2_BLOCKS, B.scratch, miss_cap, B.miss_cnt, e->d_ctr);
         else
             seg_probe_kernel<R, 0><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.a, miss_cap, B.miss_cnt, e->d_ctr);
+                s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.scratch, miss_cap, B.miss_cnt, e->d_ctr);
         hipError_t h = hipGetLastError();
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
         else stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
-        list = PieceList<R>{B.a, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
+        list = PieceList<R>{B.scratch, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
     }
     if (st == DK_OK) st = sync_counters(e, "bucketed probe");
     uint64_t n_absent = 0;

@@ -699,3 +699,51 @@ def test_per_position_kmers_match_the_oracle(rng, k, canonical):
         # empty batch
         e = d.ReadBatch.from_sequences(eng, [])
         assert len(e.kmers()["lo"]) == 0
+
+
+# ---- three partition levels: filters above 2^37 bits (2^19 segments and more) --------------------------
+
+def test_three_level_partition_forced_on_small_inputs():
+    """DK_FORCE_L3 sends every geometry with at least 8 segments through scan_part -> repart -> repart3 (the path
+    that 2^38-bit and larger filters take), so the oracle can check it at small sizes (subprocess: the switch
+    is read once per process)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = _VARIANT_SCRIPT.format(root=ROOT, tests=os.path.dirname(__file__)).replace(
+        'assert names[:2] == ["scan_part", "repart"]', 'assert names[:3] == ["scan_part", "repart", "repart3"]')
+    assert "repart3" in script
+    env = dict(os.environ, DK_FORCE_L3="1")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("set_kind", ["bloom", "exact"])
+def test_three_level_partition_at_2_to_the_38_bits(set_kind):
+    """A 32-GiB parent set (2^19 segments): the bucketed family partitions in three levels; the direct family,
+    an independent implementation working on the same geometry, must agree on the set size and on every
+    child-only k-mer and count (the oracle cannot hold a 32-GiB filter in this test's time)."""
+    d = dk()
+    n_reads, k, log2_bits = 1_500_000, 31, 38
+    gcfg = d.synth_config(genome_len=8 << 20)
+    out = {}
+    for mode in ("bucketed", "direct"):
+        with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=20260313, mode=mode, set_kind=set_kind) as eng:
+            ks = d.KmerSet(eng)
+            for smp in (0, 1):
+                ks.insert_reads(d.ReadBatch.synth(eng, gcfg, smp, 0, n_reads))
+            names = [n for n, _ in eng.timings()["stages"]]
+            if mode == "bucketed":
+                assert names[:3] == ["scan_part", "repart", "repart3"], names
+            else:
+                assert names == ["insert_direct"], names
+            pop = ks.popcount()
+            res = d.KmerCounter(eng).child_only(d.ReadBatch.synth(eng, gcfg, 2, 0, n_reads), ks)
+            names = [n for n, _ in eng.timings()["stages"]]
+            assert (names[:3] == ["scan_part", "repart", "repart3"]) if mode == "bucketed" else names[0] == "probe_direct", names
+            out[mode] = (pop, {key: res.stats[key] for key in ("n_windows", "n_valid", "n_absent", "n_distinct", "n_emitted")},
+                         _result_checksum(res))
+            res.close()
+            ks.close()
+    assert out["bucketed"] == out["direct"]
+    assert 0.02 * out["direct"][1]["n_valid"] < out["direct"][1]["n_absent"] < 0.4 * out["direct"][1]["n_valid"]
