@@ -1569,23 +1569,36 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         if (!s) e->h_ctr->n_absent = e->h_ctr->n_valid - e->h_ctr->n_ovf;   // KmerCounter: every record in a segment counts
         n_absent = e->h_ctr->n_absent;
     }
-    // overflow records (normally none): probe them one by one, sort the absent ones by segment (CSR)
-    // and hand them to seg_count as an extra list of their segment
+    // Counting units: with few absent records per filter segment (2^18 segments and more) up to four adjacent
+    // segments are counted together -- their absent lists are the "pieces" of one unit, their hashes share the
+    // top T - g bits -- so that seg_count sees ~3 K records per unit instead of a few hundred
+    int Tc = p.T;
+    uint32_t unit_pieces = 1;
+    if (st == DK_OK && s) {
+        while (unit_pieces < (uint32_t)MAX_R && Tc > 1 && (n_absent >> Tc) < 1200) {
+            Tc--;
+            unit_pieces *= 2;
+        }
+        list.n_pieces = unit_pieces;
+    }
+    const uint64_t n_units = 1ULL << Tc;
+    // overflow records (normally none): probe them one by one, sort the absent ones by counting unit (CSR)
+    // and hand them to seg_count as an extra list of their unit
     if (st == DK_OK && e->h_ctr->n_ovf) {
         const uint64_t n_ovf = e->h_ctr->n_ovf;
         st = pool_alloc(e, n_ovf * sizeof(R), (void **)&B.ovf_miss);
         if (st == DK_OK) st = pool_alloc(e, n_ovf * sizeof(R), (void **)&B.extra);
-        if (st == DK_OK) st = pool_alloc(e, (3 * p.n_seg + 1) * 4, (void **)&B.extra_idx);
+        if (st == DK_OK) st = pool_alloc(e, (3 * n_units + 1) * 4, (void **)&B.extra_idx);
         hipError_t h = hipSuccess;
         if (st == DK_OK) {
-            uint32_t *hist = B.extra_idx, *off = hist + p.n_seg, *fill = off + p.n_seg + 1;
+            uint32_t *hist = B.extra_idx, *off = hist + n_units, *fill = off + n_units + 1;
             const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
-            h = hipMemsetAsync(B.extra_idx, 0, (3 * p.n_seg + 1) * 4, e->stream);
+            h = hipMemsetAsync(B.extra_idx, 0, (3 * n_units + 1) * 4, e->stream);
             if (h == hipSuccess) {
                 ovf_probe_kernel<R><<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
                     s ? s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes,
-                    s && s->exact ? p.T : 0, p.T, B.ovf_miss, hist, e->d_ctr);
-                ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)p.n_seg);
+                    s && s->exact ? p.T : 0, Tc, B.ovf_miss, hist, e->d_ctr);
+                ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)n_units);
                 h = hipGetLastError();
             }
             if (h == hipSuccess) {
@@ -1597,7 +1610,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
             if (st == DK_OK && e->h_ctr->n_ovf_miss) {
                 const uint64_t n_om = e->h_ctr->n_ovf_miss;
                 ovf_scatter_kernel<R><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                    B.ovf_miss, n_om, p.T, off, fill, B.extra);
+                    B.ovf_miss, n_om, Tc, off, fill, B.extra);
                 h = hipGetLastError();
                 if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow scatter failed: %s", hipGetErrorString(h));
                 list.extra = B.extra;
@@ -1615,31 +1628,31 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the
         // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
         // overflow records may all sit in one segment, hence the extra room for them
-        const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, p.n_seg);
+        const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, n_units);
         const uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536 + e->h_ctr->n_ovf_miss;
         st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
         if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
         if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
         if (st == DK_OK) {
-            const uint64_t per_seg = n_absent / p.n_seg;
+            const uint64_t per_seg = n_absent / n_units;
             if (per_seg >= (WIDE ? 3500u : 7000u)) {
                 // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 2);
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 2);
                 seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
-                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
+                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             } else if (per_seg >= (WIDE ? 1300u : seg_count_mid_threshold())) {
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 6);
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 6);
                 seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
-                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
+                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             } else if (per_seg >= (WIDE ? 600u : 1200u)) {
                 // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 12);
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 12);
                 seg_count_kernel<256, 1024, 1024, WIDE><<<cgrid, 256, 0, e->stream>>>(
-                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
+                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             } else {
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(p.n_seg, (uint64_t)e->n_cu * 32);
+                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 32);
                 seg_count_kernel<128, 512, 256, WIDE><<<cgrid, 128, 0, e->stream>>>(
-                    list, p.n_seg, p.T, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
+                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
             }
             hipError_t h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
