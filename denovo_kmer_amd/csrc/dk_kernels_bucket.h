@@ -1301,7 +1301,7 @@ inline int count_segments_log2(uint64_t n_records)
 {
     static const uint64_t per_seg = [] { const char *v = getenv("DK_COUNT_SEG"); return v ? (uint64_t)atoll(v) : 5000ULL; }();
     int T = 1;
-    while (T < 2 * MAX_BIN_BITS && (n_records >> T) > per_seg) T++;
+    while (T < MAX_SEG_BITS && (n_records >> T) > per_seg) T++;       // above 18 bits: three partition levels
     return T;
 }
 
