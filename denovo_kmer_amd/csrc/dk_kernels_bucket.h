@@ -1381,6 +1381,8 @@ struct BucketBufs {
     uint64_t ovf_cap = 0;
     R *ovf_miss = nullptr, *extra = nullptr;  // probe: absent overflow records, then sorted by segment
     uint32_t *extra_idx = nullptr;            // seg_hist [n_seg] | extra_off [n_seg + 1] | fill [n_seg]
+    uint32_t *fine_cursor = nullptr;          // fill of the finer counting units (big batches, see bucketed_probe_t)
+    R *fine = nullptr;                        // their records, when the space of the probed records is too small
 };
 
 template <class R>
@@ -1393,6 +1395,8 @@ inline void free_bufs(dk_engine *e, BucketBufs<R> &B)
     pool_free(e, B.ovf_miss);
     pool_free(e, B.extra);
     pool_free(e, B.extra_idx);
+    pool_free(e, B.fine_cursor);
+    pool_free(e, B.fine);
 }
 
 // scan_part + repart (+ repart): afterwards B.rec / B.cursor2 hold every record of the batch grouped by segment,
@@ -1581,7 +1585,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         }
         list.n_pieces = unit_pieces;
     }
-    const uint64_t n_units = 1ULL << Tc;
+    uint64_t n_units = 1ULL << Tc;
     // overflow records (normally none): probe them one by one, sort the absent ones by counting unit (CSR)
     // and hand them to seg_count as an extra list of their unit
     if (st == DK_OK && e->h_ctr->n_ovf) {
@@ -1623,6 +1627,50 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         e->h_ctr->n_absent = n_absent;           // dk_probe reports it; keep the device copy in step
         hipError_t h = hipMemcpyAsync(&e->d_ctr->n_absent, &e->h_ctr->n_absent, 8, hipMemcpyHostToDevice, e->stream);
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "counter update failed: %s", hipGetErrorString(h));
+    }
+    // Big batches against a small filter leave more absent records per segment than a seg_count workgroup holds
+    // in registers (16 K), and its multi-chunk path is slow (150 ms at 16 K per segment).  The absent lists are
+    // then split once more by the next hash bits -- the level-3 use of repart, over the absent lists instead of
+    // coarse regions -- into units of ~5 K records; the space of the probed records is free for the result.
+    if (st == DK_OK && s && unit_pieces == 1 && !list.extra && p.T <= 15 && n_absent / p.n_seg > 14000) {
+        int bs = 1;
+        while (bs < MAX_BIN_BITS && (n_absent >> (p.T + bs)) > 6000) bs++;
+        const uint64_t n_fine = p.n_seg << bs;
+        const uint32_t cap_f = piece_capacity((double)n_absent / (double)n_fine, 16.0);   // an overflowing unit only costs the fallback
+        if (p.T + bs <= MAX_SEG_BITS) {
+            R *fine_out = B.rec;                  // the probed records are no longer needed
+            st = pool_alloc(e, n_fine * 4, (void **)&B.fine_cursor);
+            if (st == DK_OK && n_fine * (uint64_t)cap_f > p.n_seg * (uint64_t)p.cap2) {
+                st = pool_alloc(e, n_fine * (uint64_t)cap_f * sizeof(R), (void **)&B.fine);
+                fine_out = B.fine;
+            }
+            hipError_t h = hipSuccess;
+            if (st == DK_OK) h = hipMemsetAsync(B.fine_cursor, 0, n_fine * 4, e->stream);
+            if (st == DK_OK && h == hipSuccess) {
+                // no overflow list here: a record that does not fit bumps n_overflow and the split is abandoned
+                const OvfList<R> none{nullptr, &e->d_ctr->dbg[0], 0};
+                constexpr int TH = WIDE ? 512 : 1024;
+                const uint32_t tpp = (p.cap2 + TH * 8 - 1) / (TH * 8);
+                repart_kernel<TH, 8, 8, R><<<dim3(tpp, (unsigned)p.n_seg), TH, 0, e->stream>>>(
+                    B.scratch, B.miss_cnt, 1u, p.cap2, tpp, p.T, bs, cap_f, fine_out, B.fine_cursor, none, e->d_ctr);
+                h = hipGetLastError();
+                if (h == hipSuccess) h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
+                if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+            }
+            if (st == DK_OK && h != hipSuccess) st = fail(e, DK_ERR_HIP, "absent-list split failed: %s", hipGetErrorString(h));
+            if (st == DK_OK) {
+                stage_mark(e, "count_split");
+                if (e->h_ctr->n_overflow == 0) {
+                    list = PieceList<R>{fine_out, B.fine_cursor, 1, cap_f, nullptr, nullptr};
+                    Tc = p.T + bs;
+                    n_units = n_fine;
+                } else {                                   // a unit overflowed (heavy repeats): count the unsplit lists
+                    e->h_ctr->n_overflow = 0;
+                    h = hipMemsetAsync(&e->d_ctr->n_overflow, 0, 8, e->stream);
+                    if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h));
+                }
+            }
+        }
     }
     if (st == DK_OK && n_absent) {
         // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the

@@ -747,3 +747,22 @@ def test_three_level_partition_at_2_to_the_38_bits(set_kind):
             ks.close()
     assert out["bucketed"] == out["direct"]
     assert 0.02 * out["direct"][1]["n_valid"] < out["direct"][1]["n_absent"] < 0.4 * out["direct"][1]["n_valid"]
+
+
+@pytest.mark.parametrize("k", [31, 45])
+def test_many_absent_records_per_segment_are_split_before_counting(rng, k):
+    # 2 filter segments, ~70 K absent records: far more per segment than a count workgroup keeps in registers,
+    # so the absent lists are split by further hash bits first (stage "count_split"); results must not change
+    d = dk()
+    parents = random_reads(rng, 20, 150, 151)
+    child = random_reads(rng, 600, 150, 151)
+    child = child + child[:150] + parents[:10]
+    with make_engine("bucketed", k=k, filter_log2_bits=20, n_hashes=3, seed=12) as eng:
+        ks, ist, res = gpu_trio(eng, parents, child)
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert "count_split" in names and "overflow_redo" not in names, names
+        f, oist, km, cn, pst = oracle_trio(parents, child, k, 20, 3, 12)
+        assert np.array_equal(ks.to_host(), f)
+        assert_result_equals(res, km, cn)
+        assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
+        assert int(cn.max()) >= 2
