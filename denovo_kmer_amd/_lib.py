@@ -22,7 +22,7 @@ MODE_AUTO, MODE_DIRECT, MODE_BUCKETED = 0, 1, 2
 SET_BLOOM, SET_EXACT = 0, 1
 ERR_SET_FULL = 7
 MAX_STAGES = 12
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class DkError(RuntimeError):
@@ -79,6 +79,7 @@ SYMBOLS = {
     "dk_engine_synchronize": (C.c_int32, [_P]),
     "dk_engine_timings": (C.c_int32, [_P, C.POINTER(DkTimings)]),
     "dk_engine_config": (C.c_int32, [_P, C.POINTER(DkConfig)]),
+    "dk_engine_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dk_reads_from_ascii": (C.c_int32, [_P, _P, _P, _U64, _PP]),
     "dk_reads_from_packed": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),
     "dk_reads_attach_device": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),
@@ -109,6 +110,13 @@ SYMBOLS = {
     "dk_result_merge": (C.c_int32, [_P, _PP, C.c_uint32, C.c_uint32, _PP, C.POINTER(DkStats)]),
     "dk_result_attach": (C.c_int32, [_P, _P, _P, _P, _U64, _PP]),
     "dk_result_destroy": (None, [_P]),
+    "dk_accum_create": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32, _U64, _PP]),
+    "dk_accum_add": (C.c_int32, [_P, _P, C.POINTER(DkStats)]),
+    "dk_accum_finish": (C.c_int32, [_P, C.c_uint32, _PP, C.POINTER(DkStats)]),
+    "dk_accum_reset": (C.c_int32, [_P, C.c_uint32]),
+    "dk_accum_stats": (C.c_int32, [_P, C.POINTER(DkStats)]),
+    "dk_accum_device_bytes": (C.c_int32, [_P, _PU64]),
+    "dk_accum_destroy": (None, [_P]),
 }
 
 _lib = None

@@ -85,6 +85,11 @@ class Engine:
         self.check(self._lib.dk_engine_timings(self.handle, C.byref(t)))
         return t.as_dict()
 
+    def set_option(self, name, value):
+        """run-time option of the engine (dk_engine_set_option): "multiplicity_hint" for capacity planning, and the
+        validated test hooks that force a kernel geometry ("scan_variant", "force_l3", ...)"""
+        self.check(self._lib.dk_engine_set_option(self.handle, name.encode(), int(value)))
+
     def or_reduce_slices(self, dst_ptr, src_ptr, n_slices, slice_bytes):
         """dst |= OR of n_slices slices at src (device pointers): local step of the OR-all-reduce."""
         self.check(self._lib.dk_or_reduce_slices(self.handle, C.c_void_p(dst_ptr), C.c_void_p(src_ptr),
@@ -385,6 +390,59 @@ class KmerSet:
         if self._h:
             if self.engine._h:
                 self.engine._lib.dk_set_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ChildAccumulator:
+    """Child-only k-mers of a sample that arrives in many batches (dk_accum): the absent occurrences of every
+    batch are kept on the GPU and counted once, so counts and `min_count` are exact over the whole sample.
+
+    window_count > 1: the sample is streamed window_count times, pass w (`reset(w)`) keeping the k-mers whose hash
+    lies in the w-th of window_count equal ranges -- for samples whose absent occurrences do not fit in HBM beside
+    the set.  parents=None counts every k-mer (KmerCounter over batches)."""
+
+    def __init__(self, engine, parents, capacity_records, window_index=0, window_count=1):
+        self.engine = engine
+        self._h = C.c_void_p()
+        self._parents = parents
+        self.window_count = window_count
+        engine.check(engine._lib.dk_accum_create(engine.handle, parents._h if parents is not None else None,
+                                                 window_index, window_count, int(capacity_records), C.byref(self._h)))
+
+    def add(self, batch):
+        st = DkStats()
+        self.engine.check(self.engine._lib.dk_accum_add(self._h, batch._h, C.byref(st)))
+        return st.as_dict()
+
+    def finish(self, min_count=1):
+        h = C.c_void_p()
+        st = DkStats()
+        self.engine.check(self.engine._lib.dk_accum_finish(self._h, min_count, C.byref(h), C.byref(st)))
+        return KmerCounts(self.engine, h, st.as_dict())
+
+    def reset(self, window_index=0):
+        self.engine.check(self.engine._lib.dk_accum_reset(self._h, window_index))
+
+    def stats(self):
+        st = DkStats()
+        self.engine.check(self.engine._lib.dk_accum_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def device_bytes(self):
+        n = C.c_uint64()
+        self.engine.check(self.engine._lib.dk_accum_device_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if self._h:
+            if self.engine._h:
+                self.engine._lib.dk_accum_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -219,16 +219,17 @@ static dk_status probe_direct(dk_engine *e, dk_set *s, const dk_reads *r, dk_res
     return DK_OK;
 }
 
-template <bool WIDE>
+// Sum (k-mer, count) tables by k-mer.  The inputs are concatenated into dense candidate arrays; the index table is
+// built and emitted one hash range at a time (at most 2^31 slots per pass), with 64-bit candidate indices once the
+// inputs hold 2^32 - 1 entries or more, so the only bound is device memory (12 + 12 bytes per input entry plus
+// the pass table).  An accumulator (dk_accum_*) is the better tool for a sample that arrives in many batches.
+template <bool WIDE, class IdxT>
 static dk_status merge_results(dk_engine *e, const dk_result *const *results, uint32_t n_results, uint32_t min_count,
-                               dk_result *res)
+                               dk_result *res, uint64_t total)
 {
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n_results; i++) total += results[i]->n;
-    if (total == 0) return DK_OK;
-    if (total >= 0xFFFFFFFFULL) return fail(e, DK_ERR_OVERFLOW, "more than 2^32-1 entries to merge");
     uint64_t *lo = nullptr, *hi = nullptr;
-    uint32_t *cnt = nullptr, *slots = nullptr, *counts = nullptr;
+    uint32_t *cnt = nullptr, *counts = nullptr;
+    IdxT *slots = nullptr;
     auto cleanup = [&]() {
         pool_free(e, lo);
         pool_free(e, hi);
@@ -236,12 +237,16 @@ static dk_status merge_results(dk_engine *e, const dk_result *const *results, ui
         pool_free(e, slots);
         pool_free(e, counts);
     };
+    int pbits = e->opt.merge_pass_bits;
+    while (pbits < 16 && ((2 * total) >> pbits) > (1ULL << 31)) pbits++;
+    // pass tables are sized for the mean share of a pass plus slack (hash ranges are uniform)
+    const uint64_t per_pass = (total >> pbits) + (pbits ? (total >> (pbits + 3)) + 65536 : 0);
+    const int log2_cap = std::max(10, ceil_log2(2 * per_pass));
+    const uint64_t cap = 1ULL << log2_cap;
     dk_status st = pool_alloc(e, total * 8, (void **)&lo);
     if (st == DK_OK && WIDE) st = pool_alloc(e, total * 8, (void **)&hi);
     if (st == DK_OK) st = pool_alloc(e, total * 4, (void **)&cnt);
-    const int log2_cap = std::max(10, ceil_log2(2 * total));
-    const uint64_t cap = 1ULL << log2_cap;
-    if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&slots);
+    if (st == DK_OK) st = pool_alloc(e, cap * sizeof(IdxT), (void **)&slots);
     if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&counts);
     if (st == DK_OK) st = pool_alloc(e, total * 8, (void **)&res->d_lo);
     if (st == DK_OK && WIDE) st = pool_alloc(e, total * 8, (void **)&res->d_hi);
@@ -261,21 +266,20 @@ static dk_status merge_results(dk_engine *e, const dk_result *const *results, ui
             done += c;
         }
     }
-    if (h == hipSuccess) h = hipMemsetAsync(slots, 0xFF, cap * 4, e->stream);
-    if (h == hipSuccess) h = hipMemsetAsync(counts, 0, cap * 4, e->stream);
-    if (h == hipSuccess) {
-        merge_insert_kernel<WIDE><<<grid_for(e, total, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-            lo, hi, cnt, total, slots, counts, log2_cap, e->cfg.seed);
-        h = hipGetLastError();
-    }
-    if (h == hipSuccess) {
-        stage_mark(e, "merge_insert");
-        count_emit_kernel<WIDE><<<grid_for(e, cap, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-            lo, hi, slots, counts, cap, min_count, e->d_ctr, res->d_lo, res->d_hi, res->d_cnt);
-        h = hipGetLastError();
+    for (uint32_t q = 0; q < (1u << pbits) && h == hipSuccess; q++) {
+        h = hipMemsetAsync(slots, 0xFF, cap * sizeof(IdxT), e->stream);
+        if (h == hipSuccess) h = hipMemsetAsync(counts, 0, cap * 4, e->stream);
+        if (h == hipSuccess) {
+            merge_insert_kernel<WIDE, IdxT><<<grid_for(e, total, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                lo, hi, cnt, total, slots, counts, log2_cap, e->cfg.seed, pbits, q);
+            // entries are appended behind those of the earlier passes (Counters::n_emitted runs on)
+            count_emit_kernel<WIDE, IdxT><<<grid_for(e, cap, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                lo, hi, slots, counts, cap, min_count, e->d_ctr, res->d_lo, res->d_hi, res->d_cnt);
+            h = hipGetLastError();
+        }
     }
     if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "merge kernels failed: %s", hipGetErrorString(h)); }
-    stage_mark(e, "merge_emit");
+    stage_mark(e, "merge");
     st = read_counters(e);
     cleanup();
     if (st != DK_OK) return st;
@@ -284,6 +288,104 @@ static dk_status merge_results(dk_engine *e, const dk_result *const *results, ui
     res->region_cap = total;
     res->region_n[0] = res->n;
     return DK_OK;
+}
+
+template <bool WIDE>
+static dk_status merge_results(dk_engine *e, const dk_result *const *results, uint32_t n_results, uint32_t min_count,
+                               dk_result *res)
+{
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_results; i++) total += results[i]->n;
+    if (total == 0) return DK_OK;
+    if (total >= 0xFFFFFFFFULL || e->opt.merge_idx64) return merge_results<WIDE, uint64_t>(e, results, n_results, min_count, res, total);
+    return merge_results<WIDE, uint32_t>(e, results, n_results, min_count, res, total);
+}
+
+// the exact redo path of dk_accum_add (and the small-batch path): the direct family lists the absent k-mers of the
+// batch, which are hashed and appended to their units through global cursors
+template <bool WIDE>
+static dk_status accum_add_direct(dk_engine *e, dk_accum *a, const dk_reads *r)
+{
+    using R = typename RecOf<WIDE>::type;
+    const StreamView sv = view_of(r);
+    const FilterView fv = fview_of(e, a->s);
+    uint64_t cand_cap = std::min(r->n_bases, r->n_windows ? r->n_windows : r->n_bases);
+    if (cand_cap == 0) cand_cap = 1;
+    uint64_t *cand_lo = nullptr, *cand_hi = nullptr;
+    dk_status st = pool_alloc(e, cand_cap * 8, (void **)&cand_lo);
+    if (st == DK_OK && WIDE) st = pool_alloc(e, cand_cap * 8, (void **)&cand_hi);
+    hipError_t h = hipSuccess;
+    if (st == DK_OK) {
+        probe_direct_kernel<WIDE><<<grid_for(e, r->n_bases, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            sv, fv, (int)e->cfg.k, (int)e->cfg.canonical, e->d_ctr, cand_lo, cand_hi, cand_cap);
+        h = hipGetLastError();
+        if (h == hipSuccess) {
+            stage_mark(e, "probe_direct");
+            st = read_counters(e);
+        }
+    }
+    if (st == DK_OK && h == hipSuccess && e->h_ctr->n_cand > cand_cap)
+        st = fail(e, DK_ERR_OVERFLOW, "candidate list overflow (%llu > %llu): n_windows under-stated?",
+                  (unsigned long long)e->h_ctr->n_cand, (unsigned long long)cand_cap);
+    if (st == DK_OK && h == hipSuccess && e->h_ctr->n_cand) {
+        const uint64_t n = e->h_ctr->n_cand;
+        acc_append_kmers_kernel<WIDE><<<grid_for(e, n, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            cand_lo, cand_hi, n, e->cfg.seed, a->wbits, a->widx, accum_unit_bits(a), accum_unit_base(a), accum_out<R>(e, a), e->d_ctr);
+        h = hipGetLastError();
+        if (h == hipSuccess) stage_mark(e, "acc_append");
+    }
+    pool_free(e, cand_lo);
+    pool_free(e, cand_hi);
+    if (st == DK_OK && h != hipSuccess) st = fail(e, DK_ERR_HIP, "direct accumulate failed: %s", hipGetErrorString(h));
+    if (st == DK_OK) {
+        e->h_ctr->n_absent = 0;                                 // the direct kernel tallied every absent window, the append only those inside the window
+        h = hipMemsetAsync(&e->d_ctr->n_absent, 0, 8, e->stream);
+        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h));
+    }
+    if (st == DK_OK) st = sync_counters(e, "direct accumulate");
+    return st;
+}
+
+template <bool WIDE>
+static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, dk_result *res)
+{
+    using R = typename RecOf<WIDE>::type;
+    const int Tu = accum_unit_bits(a);
+    const uint64_t unit_base = accum_unit_base(a);
+    PieceList<R> list{(const R *)a->store, a->fill, 1, a->unit_cap, nullptr, nullptr};
+    // occurrences that found their unit full: sorted by unit (CSR) and counted with it
+    unsigned long long n_aovf = 0;
+    DK_HIP(e, hipMemcpyAsync(&n_aovf, a->d_novf, 8, hipMemcpyDeviceToHost, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    if (n_aovf > a->ovf_cap) n_aovf = a->ovf_cap;
+    R *extra = nullptr;
+    uint32_t *idx = nullptr;
+    dk_status st = DK_OK;
+    if (n_aovf) {
+        st = pool_alloc(e, n_aovf * sizeof(R), (void **)&extra);
+        if (st == DK_OK) st = pool_alloc(e, (3 * a->n_units + 1) * 4, (void **)&idx);
+        hipError_t h = hipSuccess;
+        if (st == DK_OK) {
+            uint32_t *hist = idx, *off = hist + a->n_units, *fill = off + a->n_units + 1;
+            h = hipMemsetAsync(idx, 0, (3 * a->n_units + 1) * 4, e->stream);
+            if (h == hipSuccess) {
+                unit_hist_kernel<R><<<grid_for(e, n_aovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>((const R *)a->ovf, n_aovf, Tu, unit_base, hist);
+                ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)a->n_units);
+                ovf_scatter_kernel<R><<<grid_for(e, n_aovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    (const R *)a->ovf, n_aovf, Tu, unit_base, off, fill, extra);
+                h = hipGetLastError();
+            }
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "accumulator overflow sort failed: %s", hipGetErrorString(h));
+            else stage_mark(e, "acc_ovf_sort");
+            list.extra = extra;
+            list.extra_off = off;
+        }
+    }
+    if (st == DK_OK)
+        st = bucketed_count_stage<WIDE>(e, list, a->n_units, Tu, unit_base, a->n_absent, n_aovf, min_count, min_count > 1, res);
+    pool_free(e, extra);
+    pool_free(e, idx);
+    return st;
 }
 
 #define CHECK_ARG(e, cond)                                                              \
@@ -409,6 +511,35 @@ dk_status dk_engine_config(const dk_engine *e, dk_config *out)
     return DK_OK;
 }
 
+dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, name != nullptr);
+    struct Opt { const char *name; int dk_options::*field; int64_t lo, hi; };
+    static const Opt opts[] = {
+        {"multiplicity_hint", &dk_options::multiplicity_hint, 0, 1 << 20},
+        {"scan_variant", &dk_options::scan_variant, 0, 6},
+        {"repart_variant", &dk_options::repart_variant, 0, 1},
+        {"force_l3", &dk_options::force_l3, 0, 1},
+        {"b1_up", &dk_options::b1_up, -4, 4},
+        {"count_seg", &dk_options::count_seg, 0, 1 << 30},
+        {"cnt_mid", &dk_options::cnt_mid, 0, 1 << 30},
+        {"sweep_variant", &dk_options::sweep_variant, 0, 2},
+        {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
+        {"merge_idx64", &dk_options::merge_idx64, 0, 1},
+    };
+    for (const Opt &o : opts) {
+        if (strcmp(name, o.name) != 0) continue;
+        if (value < o.lo || value > o.hi)
+            return fail(e, DK_ERR_INVALID_ARG, "option %s: %lld outside %lld..%lld", name, (long long)value, (long long)o.lo, (long long)o.hi);
+        if (!strcmp(name, "count_seg") && value != 0 && value < 64)
+            return fail(e, DK_ERR_INVALID_ARG, "option count_seg: %lld below 64", (long long)value);
+        e->opt.*(o.field) = (int)value;
+        return DK_OK;
+    }
+    return fail(e, DK_ERR_INVALID_ARG, "unknown option \"%s\"", name);
+}
+
 // ---- read batches -----------------------------------------------------------------------------
 static dk_status reads_alloc(dk_engine *e, uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out)
 {
@@ -446,6 +577,7 @@ dk_status dk_reads_from_ascii(dk_engine *e, const uint8_t *seq, const uint64_t *
     CHECK_ARG(e, offsets != nullptr || n_reads == 0);
     *out = nullptr;
     DK_HIP(e, hipSetDevice(e->device));
+    CHECK_ARG(e, n_reads == 0 || offsets[0] == 0);
     for (uint64_t i = 0; i < n_reads; i++) CHECK_ARG(e, offsets[i + 1] >= offsets[i]);
     const uint64_t n_seq = n_reads ? offsets[n_reads] : 0;
     CHECK_ARG(e, seq != nullptr || n_seq == 0);
@@ -486,6 +618,9 @@ dk_status dk_reads_from_packed(dk_engine *e, const uint64_t *bases, const uint64
     CHECK_ARG(e, out != nullptr);
     CHECK_ARG(e, (bases != nullptr && mask != nullptr) || n_bases == 0);
     *out = nullptr;
+    // the stream must end with a separator (the kernels judge a window that would run past the end by its flags)
+    if (n_bases && !((mask[(n_bases - 1) >> 6] >> (63 - ((n_bases - 1) & 63))) & 1ULL))
+        return fail(e, DK_ERR_INVALID_ARG, "packed stream does not end with a flagged separator position");
     DK_HIP(e, hipSetDevice(e->device));
     dk_reads *r = nullptr;
     DK_TRY(reads_alloc(e, n_bases, n_reads, n_windows, &r));
@@ -508,6 +643,14 @@ dk_status dk_reads_attach_device(dk_engine *e, const void *d_bases, const void *
     if (!e) return DK_ERR_INVALID_ARG;
     CHECK_ARG(e, out != nullptr);
     CHECK_ARG(e, (d_bases != nullptr && d_mask != nullptr) || n_bases == 0);
+    if (n_bases) {
+        // same requirement as dk_reads_from_packed: one word of the caller's mask is read back to check it
+        uint64_t last = 0;
+        DK_HIP(e, hipSetDevice(e->device));
+        DK_HIP(e, hipMemcpy(&last, (const uint64_t *)d_mask + ((n_bases - 1) >> 6), 8, hipMemcpyDeviceToHost));
+        if (!((last >> (63 - ((n_bases - 1) & 63))) & 1ULL))
+            return fail(e, DK_ERR_INVALID_ARG, "packed stream does not end with a flagged separator position");
+    }
     dk_reads *r = new (std::nothrow) dk_reads();
     if (!r) return fail(e, DK_ERR_OOM, "host allocation failed");
     r->e = e;
@@ -626,6 +769,10 @@ dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, ui
     CHECK_ARG(e, r != nullptr && r->e == e);
     const bool wide = e->cfg.k > 32;
     CHECK_ARG(e, r->n_bases == 0 || kmers_lo != nullptr);
+    constexpr int KT = 256;                                  // 4 waves, 35 KiB of LDS: four workgroups per CU
+    const uint64_t tile = (uint64_t)KT * (wide ? 8 : 16);
+    const uint64_t n_tiles = (r->n_bases + tile - 1) / tile;
+    if (n_tiles > 0xFFFFFFFFULL) return fail(e, DK_ERR_UNSUPPORTED, "batch too large for dk_reads_kmers");
     DK_HIP(e, hipSetDevice(e->device));
     DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
     stage_begin(e);
@@ -638,10 +785,6 @@ dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, ui
     hipError_t h = hipSuccess;
     if (st == DK_OK && r->n_bases) {
         const StreamView sv = view_of(r);
-        constexpr int KT = 256;                                  // 4 waves, 35 KiB of LDS: four workgroups per CU
-        const uint64_t tile = (uint64_t)KT * (wide ? 8 : 16);
-        const uint64_t n_tiles = (r->n_bases + tile - 1) / tile;
-        if (n_tiles > 0xFFFFFFFFULL) return fail(e, DK_ERR_UNSUPPORTED, "batch too large for dk_reads_kmers");
         const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * 4);
         if (wide)
             kmers_tile_kernel<KT, true><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
@@ -1099,6 +1242,217 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
         stats->n_windows = r->n_windows;
         stats->n_valid = e->h_ctr->n_valid;
         stats->n_absent = e->h_ctr->n_absent;
+        stats->n_distinct = e->h_ctr->n_distinct;
+        stats->n_emitted = res->n;
+    }
+    *out = res;
+    return DK_OK;
+}
+
+// ---- child-only accumulator ---------------------------------------------------------------------------------
+static dk_result *result_new(dk_engine *e)
+{
+    dk_result *res = new (std::nothrow) dk_result();
+    if (!res) return nullptr;
+    res->e = e;
+    res->d_lo = res->d_hi = nullptr;
+    res->d_cnt = nullptr;
+    res->n = 0;
+    res->n_regions = 1;
+    res->region_cap = 0;
+    memset(res->region_n, 0, sizeof res->region_n);
+    res->wide = e->cfg.k > 32;
+    res->owns = true;
+    return res;
+}
+
+static size_t accum_rec_bytes(const dk_accum *a) { return a->wide ? sizeof(Rec2) : sizeof(Rec1); }
+
+static dk_status accum_clear(dk_accum *a)
+{
+    dk_engine *e = a->e;
+    DK_HIP(e, hipMemsetAsync(a->fill, 0, a->n_units * 4, e->stream));
+    DK_HIP(e, hipMemsetAsync(a->d_novf, 0, 8, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    a->n_absent = a->n_valid = a->n_windows = a->n_reads = a->n_bases = a->n_batches = 0;
+    a->failed = false;
+    return DK_OK;
+}
+
+dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32_t window_count,
+                          uint64_t capacity_records, dk_accum **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    *out = nullptr;
+    CHECK_ARG(e, !s || s->e == e);
+    CHECK_ARG(e, window_count >= 1 && (window_count & (window_count - 1)) == 0);
+    CHECK_ARG(e, window_index < window_count);
+    CHECK_ARG(e, capacity_records >= 1);
+    const int T = set_segment_bits(e);
+    if (T < 1 || T > MAX_SEG_BITS)
+        return fail(e, DK_ERR_UNSUPPORTED, "accumulators need a set geometry of 2^20..2^%d bits", MAX_SEG_BITS + 19);
+    int wbits = 0;
+    while ((1u << wbits) < window_count) wbits++;
+    if (wbits > T - 1)
+        return fail(e, DK_ERR_INVALID_ARG, "window_count %u: at most %u windows with this set geometry (each covers at least two 64-KiB segments)",
+                    window_count, 1u << (T - 1));
+    const bool wide = e->cfg.k > 32;
+    // counting units: 2^u per segment, so that a unit's records fit the registers of one seg_count workgroup
+    const uint64_t n_seg_w = 1ULL << (T - wbits);
+    const uint64_t unit_target = wide ? 6144 : 12288;
+    int u = 0;
+    while (u < MAX_SUB_BITS && capacity_records / (n_seg_w << u) > unit_target) u++;
+    if (capacity_records / (n_seg_w << u) > unit_target)
+        return fail(e, DK_ERR_UNSUPPORTED, "capacity %llu is more than %llu records per hash window of this set geometry: use more windows",
+                    (unsigned long long)capacity_records, (unsigned long long)(unit_target * (n_seg_w << MAX_SUB_BITS)));
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_accum *a = new (std::nothrow) dk_accum();
+    if (!a) return fail(e, DK_ERR_OOM, "host allocation failed");
+    a->e = e;
+    a->s = s;
+    a->wbits = wbits;
+    a->widx = window_index;
+    a->T = T;
+    a->u = u;
+    a->n_units = n_seg_w << u;
+    a->unit_cap = piece_capacity((double)capacity_records / (double)a->n_units, 4.0);
+    a->wide = wide;
+    a->store = nullptr;
+    a->fill = nullptr;
+    a->ovf = nullptr;
+    a->d_novf = nullptr;
+    a->ovf_cap = std::max<uint64_t>(1ULL << 16, capacity_records / 64);
+    const size_t rb = accum_rec_bytes(a);
+    dk_status st = pool_alloc(e, a->n_units * (uint64_t)a->unit_cap * rb, &a->store);
+    if (st == DK_OK) st = pool_alloc(e, a->n_units * 4, (void **)&a->fill);
+    if (st == DK_OK) st = pool_alloc(e, a->ovf_cap * rb, &a->ovf);
+    if (st == DK_OK) st = pool_alloc(e, 256, (void **)&a->d_novf);
+    if (st == DK_OK) st = accum_clear(a);
+    if (st != DK_OK) { dk_accum_destroy(a); return st; }
+    *out = a;
+    return DK_OK;
+}
+
+void dk_accum_destroy(dk_accum *a)
+{
+    if (!a) return;
+    pool_free(a->e, a->store);
+    pool_free(a->e, a->fill);
+    pool_free(a->e, a->ovf);
+    pool_free(a->e, a->d_novf);
+    delete a;
+}
+
+dk_status dk_accum_reset(dk_accum *a, uint32_t window_index)
+{
+    if (!a) return DK_ERR_INVALID_ARG;
+    dk_engine *e = a->e;
+    CHECK_ARG(e, window_index < (1u << a->wbits));
+    DK_HIP(e, hipSetDevice(e->device));
+    a->widx = window_index;
+    return accum_clear(a);
+}
+
+dk_status dk_accum_stats(const dk_accum *a, dk_stats *out)
+{
+    if (!a || !out) return DK_ERR_INVALID_ARG;
+    memset(out, 0, sizeof *out);
+    out->n_reads = a->n_reads;
+    out->n_bases = a->n_bases;
+    out->n_windows = a->n_windows;
+    out->n_valid = a->n_valid;
+    out->n_absent = a->n_absent;
+    return DK_OK;
+}
+
+dk_status dk_accum_device_bytes(const dk_accum *a, uint64_t *n_bytes)
+{
+    if (!a || !n_bytes) return DK_ERR_INVALID_ARG;
+    const size_t rb = a->wide ? sizeof(Rec2) : sizeof(Rec1);
+    *n_bytes = a->n_units * (uint64_t)a->unit_cap * rb + a->n_units * 4 + a->ovf_cap * rb + 256;
+    return DK_OK;
+}
+
+dk_status dk_accum_add(dk_accum *a, const dk_reads *r, dk_stats *stats)
+{
+    if (!a || !r) return DK_ERR_INVALID_ARG;
+    dk_engine *e = a->e;
+    CHECK_ARG(e, r->e == e);
+    if (a->failed) return fail(e, DK_ERR_OVERFLOW, "the accumulator lost records in an earlier call: dk_accum_reset it first");
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
+    memset(e->h_ctr, 0, sizeof(Counters));
+    stage_begin(e);
+    dk_status st = DK_OK;
+    if (r->n_bases) {
+        bool direct = e->cfg.mode == DK_MODE_DIRECT ||
+                      (e->cfg.mode == DK_MODE_AUTO && (a->s ? !dk::bucketed_pays(e, r->n_bases, a->wbits) : r->n_bases < (1ULL << 22)));
+        if (!direct) {
+            bool appended = false;
+            st = e->cfg.k > 32 ? dk::bucketed_accum_add_t<true>(e, a, r, &appended) : dk::bucketed_accum_add_t<false>(e, a, r, &appended);
+            if (st == DK_ERR_OVERFLOW && !appended) {
+                // the partition lost records before anything was appended: redo the batch exactly
+                hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+                st = h == hipSuccess ? DK_OK : fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h));
+                memset(e->h_ctr, 0, sizeof(Counters));
+                stage_mark(e, "overflow_redo");
+                direct = true;
+            } else if (st != DK_OK && appended) {
+                a->failed = true;
+            }
+        }
+        if (direct && st == DK_OK) {
+            st = e->cfg.k > 32 ? accum_add_direct<true>(e, a, r) : accum_add_direct<false>(e, a, r);
+            if (st != DK_OK) a->failed = true;
+        }
+    }
+    if (st == DK_ERR_OVERFLOW && a->failed)
+        st = fail(e, DK_ERR_OVERFLOW, "accumulator full: %llu occurrences found neither room in their unit nor in the overflow list "
+                  "(capacity too small for this sample: use more windows or a larger capacity)", (unsigned long long)e->h_ctr->n_overflow);
+    if (st == DK_OK) st = stage_end(e);
+    if (st != DK_OK) return st;
+    a->n_batches++;
+    a->n_reads += r->n_reads;
+    a->n_bases += r->n_bases;
+    a->n_windows += r->n_windows;
+    a->n_valid += e->h_ctr->n_valid;
+    a->n_absent += e->h_ctr->n_absent;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = r->n_reads;
+        stats->n_bases = r->n_bases;
+        stats->n_windows = r->n_windows;
+        stats->n_valid = e->h_ctr->n_valid;
+        stats->n_absent = e->h_ctr->n_absent;
+    }
+    return DK_OK;
+}
+
+dk_status dk_accum_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_stats *stats)
+{
+    if (!a) return DK_ERR_INVALID_ARG;
+    dk_engine *e = a->e;
+    CHECK_ARG(e, out != nullptr && min_count >= 1);
+    *out = nullptr;
+    if (a->failed) return fail(e, DK_ERR_OVERFLOW, "the accumulator lost records in an earlier call: dk_accum_reset it first");
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_result *res = result_new(e);
+    if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
+    hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+    if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
+    memset(e->h_ctr, 0, sizeof(Counters));
+    stage_begin(e);
+    dk_status st = a->wide ? accum_finish_t<true>(e, a, min_count, res) : accum_finish_t<false>(e, a, min_count, res);
+    if (st == DK_OK) st = stage_end(e);
+    if (st != DK_OK) { dk_result_destroy(res); return st; }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = a->n_reads;
+        stats->n_bases = a->n_bases;
+        stats->n_windows = a->n_windows;
+        stats->n_valid = a->n_valid;
+        stats->n_absent = a->n_absent;
         stats->n_distinct = e->h_ctr->n_distinct;
         stats->n_emitted = res->n;
     }

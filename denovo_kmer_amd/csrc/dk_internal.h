@@ -14,8 +14,24 @@ struct dk_pool_block {
     bool in_use;
 };
 
+// Run-time options of an engine (dk_engine_set_option): the capacity hint is for callers, the rest are the
+// test hooks that force a kernel geometry on inputs too small to select it (validated; 0 = automatic).
+struct dk_options {
+    int multiplicity_hint = 0;    // expected copies of one k-mer inside one batch (0 = assume up to 64)
+    int scan_variant = 0;         // scan_part tile geometry 1..6
+    int repart_variant = 0;       // 1 = 1024 x 16 repart tiles
+    int force_l3 = 0;             // three partition levels from 8 segments on
+    int b1_up = 0;                // shift the level-1 / level-2 bit split
+    int count_seg = 0;            // KmerCounter: records per counting segment (default 5000)
+    int cnt_mid = 0;              // seg_count: threshold of the 512-thread geometry (default 3600)
+    int sweep_variant = 0;        // segment kernels: 1 = one workgroup per segment, 2 = persistent walk
+    int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes
+    int merge_idx64 = 0;          // dk_result_merge: 64-bit candidate indices whatever the size
+};
+
 struct dk_engine {
     dk_config cfg;
+    dk_options opt;
     int device;
     int n_cu;
     hipStream_t stream;
@@ -45,6 +61,27 @@ struct dk_set {
     uint64_t n_bytes;
     bool owns;
     bool exact;                   // DK_SET_EXACT: d_words is read as open-addressing tables (dk_device.h)
+};
+
+// Child-only accumulator (dk_accum_*): the absent k-mer occurrences of many batches, kept as bucket records
+// grouped by counting unit (a hash-prefix range) and counted once by dk_accum_finish.
+struct dk_accum {
+    dk_engine *e;
+    dk_set *s;                    // parent set (NULL: every k-mer counts, KmerCounter over many batches)
+    int wbits;                    // the accumulator covers the hashes whose top wbits equal widx
+    uint32_t widx;
+    int T;                        // segment bits of the engine's set geometry (all windows together)
+    int u;                        // counting units per segment = 2^u
+    uint64_t n_units;             // 2^(T - wbits + u)
+    uint32_t unit_cap;            // records per unit
+    void *store;                  // n_units * unit_cap records (Rec1 / Rec2)
+    uint32_t *fill;               // records held per unit
+    void *ovf;                    // records that found their unit full (counted with the unit at the end)
+    uint64_t ovf_cap;
+    unsigned long long *d_novf;   // device counter of the overflow list
+    uint64_t n_absent, n_valid, n_windows, n_reads, n_bases, n_batches;
+    bool wide;
+    bool failed;                  // a batch lost records (overflow list full) or died half-way: reset before reuse
 };
 
 struct dk_result {

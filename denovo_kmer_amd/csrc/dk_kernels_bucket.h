@@ -198,11 +198,13 @@ __device__ __forceinline__ void multisplit_finish(SplitLds<THREADS, PER_THREAD, 
 // the stage as per-bin runs.  The copy-out of tile i (LDS reads + global stores) is interleaved,
 // record by record, with the count phase of tile i+1 (pure VALU + one LDS atomic), so the LDS and
 // store latency of one hides behind the hashing of the other inside every wave.
-template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE>
+// WINDOWED: only the k-mers whose hash starts with the wbits (>= 1) bits of widx become records (a hash-range pass of
+// dk_accum_add); the bins are then taken from the b1 bits after the window's.
+template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE, bool WINDOWED>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
                  typename RecOf<WIDE>::type *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles,
-                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr)
+                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx)
 {
     using R = typename RecOf<WIDE>::type;
     constexpr int TILE = THREADS * PER_THREAD;
@@ -211,9 +213,14 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
     const int nbins = 1 << b1;
-    const int shift = 64 - b1;
-    auto bin_of = [=](uint64_t h) -> uint32_t { return b1 ? (uint32_t)(h >> shift) : 0u; };
+    const int shift = 64 - b1 - (WINDOWED ? wbits : 0);
+    const int wshift = 64 - wbits;                       // WINDOWED only (wbits >= 1)
+    auto bin_of = [=](uint64_t h) -> uint32_t {
+        if constexpr (WINDOWED) return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1);
+        else return b1 ? (uint32_t)(h >> shift) : 0u;
+    };
     uint32_t n_records = 0, n_overflow = 0;
+    uint32_t n_all = 0;                                   // WINDOWED: valid windows inside or outside the window
     multisplit_init(L, nbins);
     Stamps st;
 
@@ -290,8 +297,14 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         }
         rec.h = fmix64(kl ^ hash_tweak<WIDE>(kh, seed));
         if constexpr (WIDE) rec.hi = kh;
-        if constexpr (!WIDE) return (okbits >> (PER_THREAD - 1 - j)) & 1u;
-        else return !bad && p0 + j < s.n_bases;
+        bool ok;
+        if constexpr (!WIDE) ok = (okbits >> (PER_THREAD - 1 - j)) & 1u;
+        else ok = !bad && p0 + j < s.n_bases;
+        if constexpr (WINDOWED) {
+            n_all += ok;
+            ok = ok && (uint32_t)(rec.h >> wshift) == widx;
+        }
+        return ok;
     };
 
     uint32_t tile = blockIdx.x;
@@ -402,7 +415,13 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     }
     st.flush(ctr, 0);
     multisplit_finish(L, nbins, 0, (uint32_t)G, (uint32_t)w, capw, cnt1);
-    if (tid == 0 && n_records) atomicAdd(&ctr->n_valid, (unsigned long long)n_records);
+    if constexpr (WINDOWED) {
+        if (tid == 0 && n_records) atomicAdd(&ctr->n_in_window, (unsigned long long)n_records);
+        n_all = wave_total(n_all);
+        if (lane_id() == 0 && n_all) atomicAdd(&ctr->n_valid, (unsigned long long)n_all);
+    } else {
+        if (tid == 0 && n_records) atomicAdd(&ctr->n_valid, (unsigned long long)n_records);
+    }
     n_overflow = (uint32_t)wave_sum(n_overflow);
     if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
 }
@@ -749,27 +768,107 @@ seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int
     for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += SEG_THREADS) dst[i] = s4[i];
 }
 
-// absent records of segment s are written to miss[s * miss_cap ...], their number to miss_cnt[s]
+// Where the absent records of a segment go.
+//   per batch (ACC = false): recs[seg * cap ...], compacted per wave by ballot; cnt[seg] = their number
+//   accumulate (ACC = true, dk_accum_add): the accumulator's counting units of the segment -- unit = seg << sub_bits |
+//     the next sub_bits hash bits -- appended behind cnt[unit], which persists from batch to batch; a record whose unit
+//     is full goes to the accumulator's overflow list
+// seg = the segment's index inside the window (= blockIdx.x); the filter is addressed with seg_base + seg.
+template <class R>
+struct MissOut {
+    R *recs;
+    uint32_t cap;
+    uint32_t *cnt;
+    int sub_bits, sub_shift;
+    OvfList<R> ovf;
+};
+constexpr int MAX_SUB_BITS = 6;
+
+template <class R, bool ACC>
+struct MissSink {
+    uint32_t *sfill;       // LDS: ACC: fill of the segment's units; else [0] = absent records so far
+    R *dst;
+    const MissOut<R> &mo;
+    uint64_t seg;
+    uint32_t n_dropped = 0;
+    __device__ __forceinline__ MissSink(uint32_t *lds, const MissOut<R> &m, uint64_t seg_local) : sfill(lds), mo(m), seg(seg_local)
+    {
+        if constexpr (ACC) {
+            dst = m.recs + (seg_local << m.sub_bits) * (uint64_t)m.cap;
+            if (threadIdx.x < (1u << m.sub_bits)) sfill[threadIdx.x] = m.cnt[(seg_local << m.sub_bits) + threadIdx.x];
+            if (threadIdx.x == 64) sfill[64] = 0;                          // [64] = absent records of this batch
+        } else {
+            dst = m.recs + seg_local * (uint64_t)m.cap;
+            if (threadIdx.x == 0) sfill[0] = 0;
+        }
+    }
+    // every lane of the wave calls this (ballots inside)
+    __device__ __forceinline__ void put(bool absent, const R &rec)
+    {
+        if constexpr (ACC) {
+            uint32_t sub = 0, pos = 0;
+            if (absent) {
+                sub = (uint32_t)(rec.h >> mo.sub_shift) & ((1u << mo.sub_bits) - 1u);
+                pos = atomicAdd(&sfill[sub], 1u);
+            }
+            const bool full = absent && pos >= mo.cap;
+            if (absent && !full) dst[(uint64_t)sub * mo.cap + pos] = rec;
+            if (__ballot(full)) ovf_append(mo.ovf, full, rec, n_dropped);
+        } else {
+            const uint64_t b = __ballot(absent);
+            if (b) {
+                const int leader = __ffsll((long long)b) - 1;
+                uint32_t wbase = 0;
+                if (lane_id() == leader) wbase = atomicAdd(&sfill[0], (uint32_t)__popcll(b));
+                wbase = __shfl(wbase, leader);
+                if (absent) dst[wbase + popc_below(b)] = rec;
+            }
+        }
+    }
+    // after a workgroup barrier; my_absent = absent records this thread saw (ACC only)
+    __device__ __forceinline__ void finish(Counters *ctr, uint32_t my_absent)
+    {
+        if constexpr (ACC) {
+            const uint32_t ws = wave_total(my_absent);
+            if (lane_id() == 0 && ws) atomicAdd(&sfill[64], ws);
+            __syncthreads();
+            if (threadIdx.x < (1u << mo.sub_bits)) {
+                const uint32_t f = sfill[threadIdx.x];
+                mo.cnt[(seg << mo.sub_bits) + threadIdx.x] = f < mo.cap ? f : mo.cap;
+            }
+            if (threadIdx.x == 0 && sfill[64]) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)sfill[64]);
+            n_dropped = (uint32_t)wave_sum(n_dropped);
+            if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
+        } else {
+            if (threadIdx.x == 0) {
+                mo.cnt[seg] = sfill[0];
+                if (sfill[0]) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)sfill[0]);
+            }
+        }
+    }
+};
+
 // NH > 0: the number of hash bits is a compile-time constant (the four LDS reads of a record are then
 // issued back to back instead of one by one behind the short-circuit test); NH == 0: n_hashes at run time
-template <class R, int NH>
+template <class R, int NH, bool ACC>
 __global__ void __launch_bounds__(SEG_THREADS)
 seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
-                 R *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
+                 uint64_t seg_base, MissOut<R> mo, Counters *ctr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
-    __shared__ uint32_t n_miss;
+    __shared__ uint32_t sfill[ACC ? 65 : 1];
     const uint64_t seg_id = blockIdx.x;
     const SegPieces<R> sp = seg_pieces(pl, seg_id);
     const uint32_t n = sp.total();
     if (n == 0) {
-        if (threadIdx.x == 0) miss_cnt[seg_id] = 0;
+        if (!ACC && threadIdx.x == 0) mo.cnt[seg_id] = 0;
         return;
     }
-    if (threadIdx.x == 0) n_miss = 0;
-    load_segment(seg, filter, seg_id);
+    MissSink<R, ACC> sink(sfill, mo, seg_id);
+    const bool no_set = filter == nullptr;    // accumulating KmerCounter: every record counts as absent
+    if (!no_set) load_segment(seg, filter, seg_base + seg_id);
     __syncthreads();
-    R *dst = miss + seg_id * miss_cap;
+    uint32_t my_absent = 0;
     constexpr int UNROLL = 8;                 // records in flight per thread: loads first, then the LDS tests
     for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
         R rec[UNROLL];
@@ -795,27 +894,19 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
                 }
                 all = acc & 1u;
             } else {
+                all = !no_set;
                 for (int j = 0; j < n_hashes; j++) {
                     const uint32_t bit = (a + (uint32_t)j * d) & 511;
                     all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
                 }
             }
             const bool absent = have[u] && !all;
-            const uint64_t b = __ballot(absent);
-            if (b) {
-                const int leader = __ffsll((long long)b) - 1;
-                uint32_t wbase = 0;
-                if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
-                wbase = __shfl(wbase, leader);
-                if (absent) dst[wbase + popc_below(b)] = rec[u];
-            }
+            my_absent += absent;
+            sink.put(absent, rec[u]);
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        miss_cnt[seg_id] = n_miss;
-        if (n_miss) atomicAdd(&ctr->n_absent, (unsigned long long)n_miss);
-    }
+    sink.finish(ctr, my_absent);
 }
 
 // ---- exact set: the segment is an open-addressing table (dk_device.h) -----------------------------
@@ -861,26 +952,26 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
 // walk over the segments with the table and the records fetched in one round trip measured 6.8 ms
 // against 5.1 ms for this form at 2^17 segments: the hardware's workgroup scheduler overlaps the
 // segments' load / probe phases better than two resident persistent workgroups per CU do.)
-template <class R>
+template <class R, bool ACC>
 __global__ void __launch_bounds__(SEG_THREADS)
-seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T,
-                          R *__restrict__ miss, uint32_t miss_cap, uint32_t *__restrict__ miss_cnt, Counters *ctr)
+seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T, uint64_t seg_base,
+                       MissOut<R> mo, Counters *ctr)
 {
     constexpr bool WIDE = sizeof(R) == 16;
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
-    __shared__ uint32_t n_miss;
+    __shared__ uint32_t sfill[ACC ? 65 : 1];
     const uint64_t seg_id = blockIdx.x;
     const SegPieces<R> sp = seg_pieces(pl, seg_id);
     const uint32_t n = sp.total();
     if (n == 0) {
-        if (threadIdx.x == 0) miss_cnt[seg_id] = 0;
+        if (!ACC && threadIdx.x == 0) mo.cnt[seg_id] = 0;
         return;
     }
-    if (threadIdx.x == 0) n_miss = 0;
-    load_segment((uint32_t *)tab, table, seg_id);
+    MissSink<R, ACC> sink(sfill, mo, seg_id);
+    load_segment((uint32_t *)tab, table, seg_base + seg_id);
     __syncthreads();
-    const uint64_t EMPTY = exact_empty(seg_id, T);
-    R *dst = miss + seg_id * miss_cap;
+    const uint64_t EMPTY = exact_empty(seg_base + seg_id, T);
+    uint32_t my_absent = 0;
     constexpr int UNROLL = 8;
     for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
         R rec[UNROLL];
@@ -894,21 +985,12 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const bool absent = have[u] && !exact_find<WIDE>(tab, EMPTY, rec[u].h, rec_hi(rec[u]));
-            const uint64_t b = __ballot(absent);
-            if (b) {
-                const int leader = __ffsll((long long)b) - 1;
-                uint32_t wbase = 0;
-                if (lane_id() == leader) wbase = atomicAdd(&n_miss, (uint32_t)__popcll(b));
-                wbase = __shfl(wbase, leader);
-                if (absent) dst[wbase + popc_below(b)] = rec[u];
-            }
+            my_absent += absent;
+            sink.put(absent, rec[u]);
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        miss_cnt[seg_id] = n_miss;
-        if (n_miss) atomicAdd(&ctr->n_absent, (unsigned long long)n_miss);
-    }
+    sink.finish(ctr, my_absent);
 }
 
 // Union of table slices, the exact-set counterpart of or_slices_kernel: segment (first_seg + blockIdx.x)
@@ -959,8 +1041,11 @@ template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE>
 __global__ void __launch_bounds__(CNT_THREADS)
 seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
                  uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
-                 uint32_t *__restrict__ out_cnt, Counters *ctr)
+                 uint32_t *__restrict__ out_cnt, Counters *ctr, uint64_t unit_base, int dry)
 {
+    // unit_base: the units counted are unit_base .. unit_base + n_seg of the 2^T hash-prefix ranges (a window of
+    // an accumulator); dry: count the entries each region would receive (region_fill) without writing any --
+    // dk_accum_finish sizes the table of a min_count > 1 pass with it
     using R = typename RecOf<WIDE>::type;
     constexpr int CNT_RPT = (WIDE && CNT_THREADS < 1024) ? 8 : 16;   // records held per thread (the 1024-thread geometry runs one workgroup per CU: 128 VGPRs)
     constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
@@ -996,7 +1081,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         const SegPieces<R> sp = seg_pieces(pl, seg_id);
         const uint32_t n = sp.total();
         if (n == 0) continue;
-        const unsigned long long EMPTY = WIDE ? 0ULL : (unsigned long long)(seg_id ^ 1ULL) << (64 - T);
+        const unsigned long long EMPTY = WIDE ? 0ULL : (unsigned long long)((seg_id + unit_base) ^ 1ULL) << (64 - T);
         const uint32_t n_chunks = (n + CNT_CHUNK - 1) / CNT_CHUNK;
         const bool single = n_chunks == 1;                 // the common case: the records stay in registers
         R hv[CNT_RPT];
@@ -1076,7 +1161,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 for (int u = 0; u < CNT_RPT; u++) {
                     const bool uniq = have(c, u) && !flagged(u, hv[u]);
                     const uint64_t bal = __ballot(uniq);
-                    if (uniq) {
+                    if (uniq && !dry) {
                         const uint64_t pos = o + (uint64_t)popc_below(bal);
                         if (pos < region_cap) {
                             out_kmer[region_base + pos] = rec_lo(hv[u], seed);
@@ -1152,7 +1237,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 __syncthreads();
                 uint64_t o = gbase + ex;
                 for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS) {
-                    if (keys[sl] != EMPTY && cnts[sl] >= min_count) {
+                    if (keys[sl] != EMPTY && cnts[sl] >= min_count && !dry) {
                         if (o < region_cap) {
                             if constexpr (WIDE) {
                                 const Rec2 kr{key_h[sl], key_hi[sl]};
@@ -1221,7 +1306,7 @@ ovf_insert_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, i
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes, int exact_T, int T,
-                 R *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
+                 uint64_t unit_base, R *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
 {
     unsigned long long n = *ovf.count;
     if (n > ovf.cap) n = ovf.cap;
@@ -1237,7 +1322,7 @@ ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, in
         const uint64_t slot = wave_append(absent, &ctr->n_ovf_miss);
         if (absent) {
             miss[slot] = rec;
-            atomicAdd(&seg_hist[rec.h >> (64 - T)], 1u);
+            if (seg_hist) atomicAdd(&seg_hist[(rec.h >> (64 - T)) - unit_base], 1u);
         }
     }
 }
@@ -1257,17 +1342,89 @@ ovf_scan_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ off, u
     if (threadIdx.x == 0) off[n] = total;
 }
 
-// place the absent overflow records into their segment's slice
+// place the absent overflow records into their unit's slice (unit = top T hash bits - unit_base)
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-ovf_scatter_kernel(const R *__restrict__ miss, uint64_t n, int T, const uint32_t *__restrict__ off,
+ovf_scatter_kernel(const R *__restrict__ miss, uint64_t n, int T, uint64_t unit_base, const uint32_t *__restrict__ off,
                    uint32_t *fill, R *__restrict__ extra)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const R rec = miss[i];
-        const uint64_t seg = rec.h >> (64 - T);
+        const uint64_t seg = (rec.h >> (64 - T)) - unit_base;
         extra[off[seg] + atomicAdd(&fill[seg], 1u)] = rec;
+    }
+}
+
+// ---- accumulator (dk_accum_*): rare-path appends through global cursors -------------------------------------
+// histogram of a record list over the accumulator's units (CSR build of its overflow list at finish)
+template <class R>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+unit_hist_kernel(const R *__restrict__ recs, uint64_t n, int T, uint64_t unit_base, uint32_t *hist)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        atomicAdd(&hist[(recs[i].h >> (64 - T)) - unit_base], 1u);
+}
+
+// append records (all of them absent, all inside the window) to their units: the absent overflow records of a batch
+template <class R>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+acc_append_kernel(const R *__restrict__ recs, uint64_t n, int T, uint64_t unit_base, MissOut<R> mo, Counters *ctr)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (n + 63) & ~63ULL;
+    uint32_t n_dropped = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool have = i < n;
+        const R rec = recs[have ? i : 0];
+        bool full = false;
+        if (have) {
+            const uint64_t unit = (rec.h >> (64 - T)) - unit_base;
+            const uint32_t pos = atomicAdd(&mo.cnt[unit], 1u);       // may run past cap: readers clamp
+            full = pos >= mo.cap;
+            if (!full) mo.recs[unit * mo.cap + pos] = rec;
+        }
+        if (__ballot(full)) ovf_append(mo.ovf, full, rec, n_dropped);
+    }
+    n_dropped = (uint32_t)wave_sum(n_dropped);
+    if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
+}
+
+// the same for k-mers (the candidate list of the direct family: the exact redo path of a batch whose partition
+// overflowed); k-mers outside the window are skipped; the appended ones are tallied in Counters::shard
+template <bool WIDE>
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+acc_append_kmers_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, uint64_t n, uint64_t seed,
+                        int wbits, uint32_t widx, int T, uint64_t unit_base, MissOut<typename RecOf<WIDE>::type> mo, Counters *ctr)
+{
+    using R = typename RecOf<WIDE>::type;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (n + 63) & ~63ULL;
+    uint32_t n_dropped = 0;
+    uint64_t n_in = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool have = i < n;
+        R rec;
+        const uint64_t khi = (WIDE && have) ? hi[i] : 0;
+        rec.h = fmix64((have ? lo[i] : 0) ^ hash_tweak<WIDE>(khi, seed));
+        if constexpr (WIDE) rec.hi = khi;
+        if (wbits && (uint32_t)(rec.h >> (64 - wbits)) != widx) have = false;
+        bool full = false;
+        if (have) {
+            n_in++;
+            const uint64_t unit = (rec.h >> (64 - T)) - unit_base;
+            const uint32_t pos = atomicAdd(&mo.cnt[unit], 1u);
+            full = pos >= mo.cap;
+            if (!full) mo.recs[unit * mo.cap + pos] = rec;
+        }
+        if (__ballot(full)) ovf_append(mo.ovf, full, rec, n_dropped);
+    }
+    n_dropped = (uint32_t)wave_sum(n_dropped);
+    n_in = wave_sum(n_in);
+    if (lane_id() == 0) {
+        if (n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
+        if (n_in) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)n_in);
     }
 }
 
@@ -1276,7 +1433,9 @@ ovf_scatter_kernel(const R *__restrict__ miss, uint64_t n, int T, const uint32_t
 // (coverage, repeats) lands all its copies in one segment, so the variance is mean * ratio with
 // ratio = E[m^2]/E[m].  Level-1 pieces see 1/G of the reads, so copies of one k-mer rarely meet
 // there (ratio 4 allowed); level-2 pieces gather a whole segment (ratio 64 allowed, 30-60x
-// coverage).  Anything heavier (poly-A style heavy hitters) overflows, is detected, and the batch
+// coverage; dk_engine_set_option("multiplicity_hint") lowers it for batches that cover the genome
+// only a few times, e.g. one of the ~40 batches of a 30x whole-genome sample).  Anything heavier
+// (poly-A style heavy hitters) goes to the overflow list, and if that overflows too the batch
 // is redone exactly by the direct family.
 inline uint32_t piece_capacity(double mean, double ratio)
 {
@@ -1284,53 +1443,73 @@ inline uint32_t piece_capacity(double mean, double ratio)
     return (uint32_t)((uint64_t)(c + 1.0) + 1) & ~1u;
 }
 
+inline double segment_ratio(const dk_engine *e)
+{
+    const int m = e->opt.multiplicity_hint;
+    return m > 0 ? std::min(64.0, std::max(2.0, (double)m + 1.0)) : 64.0;
+}
+
 // scan_part geometry: 2 = 512 threads x 16 positions, two workgroups per CU (default); 6 = 1024 x 16, one
 // per CU, from 256 level-1 bins (2^16 segments) on -- with 256-512 level-1 bins the 8192-record tile leaves 16-32
 // records per run and half-empty level-1 pieces, which the 16384-record tile and half as many
-// workgroups repair (2^37 bits: 61 -> 76 Gk-mers/s).  DK_SCAN_VARIANT forces one (1, 3, 4, 5: experiments).
-inline int scan_variant(int b1)
+// workgroups repair (2^37 bits: 61 -> 76 Gk-mers/s).  Option "scan_variant" forces one (1, 3, 4, 5: experiments).
+inline int scan_variant_threads(int v) { return v == 2 || v == 3 ? 512 : v == 4 ? 256 : v == 5 ? 128 : 1024; }
+inline int scan_variant(const dk_engine *e, int b1, bool windowed)
 {
-    static const int forced = [] { const char *e = getenv("DK_SCAN_VARIANT"); return e ? atoi(e) : 0; }();
+    const int forced = windowed ? 0 : e->opt.scan_variant;       // the windowed scan is built for the two default shapes
     return forced ? forced : b1 >= 8 ? 6 : 2;
 }
 
 // KmerCounter (no set): the segments are only counting units, so their number follows the batch, not the
 // filter -- about 5 K records each, which one seg_count workgroup holds in registers (46 K records per
 // segment at the filter's 2^15 segments took 750 ms at configs[1], 2^18 segments take 9)
-inline int count_segments_log2(uint64_t n_records)
+inline int count_segments_log2(const dk_engine *e, uint64_t n_records)
 {
-    static const uint64_t per_seg = [] { const char *v = getenv("DK_COUNT_SEG"); return v ? (uint64_t)atoll(v) : 5000ULL; }();
+    const uint64_t per_seg = e->opt.count_seg > 0 ? (uint64_t)e->opt.count_seg : 5000ULL;
     int T = 1;
     while (T < MAX_SEG_BITS && (n_records >> T) > per_seg) T++;       // above 18 bits: three partition levels
     return T;
 }
 
-// T_override > 0: number of segment bits to use instead of the filter's
-inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0)
+inline int set_segment_bits(const dk_engine *e) { return (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS; }
+
+// T_override > 0: number of segment bits to use instead of the filter's.  wbits > 0: only the records of one
+// hash window (1 / 2^wbits of them) are partitioned, over the T - wbits segment bits below the window's.
+inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0, int wbits = 0)
 {
     const bool wide = e->cfg.k > 32;
-    p->T = T_override > 0 ? T_override : (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
+    p->T = (T_override > 0 ? T_override : set_segment_bits(e)) - wbits;
     if (p->T < 1 || p->T > MAX_SEG_BITS) return false;
-    static const int b1_up = [] { const char *v = getenv("DK_B1_UP"); return v ? atoi(v) : 0; }();
-    static const int force3 = [] { const char *v = getenv("DK_FORCE_L3"); return v ? atoi(v) : 0; }();
     p->b3 = 0;
     p->capA = 0;
-    if (p->T > 2 * MAX_BIN_BITS || (force3 && p->T >= 3)) {
+    if (p->T > 2 * MAX_BIN_BITS || (e->opt.force_l3 && p->T >= 3)) {
         // three levels: thirds of T; the coarse regions (b1 + b2 bits) index the grid's y dimension
         p->b1 = p->T / 3;
         p->b2 = (p->T - p->b1) / 2;
         p->b3 = p->T - p->b1 - p->b2;
     } else {
-        p->b1 = (p->T + b1_up) / 2;
+        p->b1 = (p->T + e->opt.b1_up) / 2;
         if (p->b1 > MAX_BIN_BITS) p->b1 = MAX_BIN_BITS;
         if (p->T - p->b1 > MAX_BIN_BITS) p->b1 = p->T - MAX_BIN_BITS;
         p->b2 = p->T - p->b1;
     }
+    int v = scan_variant(e, p->b1, wbits > 0);
+    if (!wide && !p->b3 && (1 << p->b1) > scan_variant_threads(v)) {
+        // a forced geometry with fewer threads than level-1 bins (the bin scan is one thread per bin): move bits to level 2
+        int t = 0;
+        while ((2 << t) <= scan_variant_threads(v)) t++;
+        if (p->T - t > MAX_BIN_BITS) v = scan_variant(e, p->b1, true);   // cannot: fall back to the automatic geometry
+        else { p->b1 = t; p->b2 = p->T - t; }
+    }
+    p->variant = v;
     p->p1 = 1u << p->b1;
     p->p2 = 1u << p->b2;
     p->n_seg = 1ULL << p->T;
-    p->n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
-    const int v = p->variant = scan_variant(p->b1);
+    const uint64_t n_all = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
+    // a window holds 1 / 2^wbits of the hashes (uniform), plus every copy of the heavy k-mers that fall into it
+    const double n_exp = (double)n_all / (double)(1ULL << wbits);
+    p->n_max = wbits ? (uint64_t)(n_exp + 8.0 * sqrt(n_exp * 64.0) + 65536.0) : n_all;
+    if (p->n_max > n_all) p->n_max = n_all;
     // 16-byte records (k > 32): 512 threads x 8 positions so that the LDS stage stays at 64 KiB
     p->tile = wide ? 512 * 8 : v == 2 ? 512 * 16 : v == 3 ? 512 * 8 : v == 4 ? 256 * 16 : v == 5 ? 128 * 16 : v == 6 ? 1024 * 16 : 1024 * 8;
     const int blocks_per_cu = wide ? 2 : v == 1 ? 1 : v == 3 ? 4 : v == 4 ? 4 : v == 5 ? 6 : v == 6 ? 1 : 2;
@@ -1340,16 +1519,17 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     // expected piece size from the largest share a producer can get (tiles are dealt round-robin,
     // so shares differ by at most one tile)
     const uint64_t tiles_per_wg = (n_tiles + p->G - 1) / p->G;
-    const double share1 = (double)std::min<uint64_t>(p->n_max, tiles_per_wg * (uint64_t)p->tile);
+    const double share1 = std::min((double)p->n_max, (double)(tiles_per_wg * (uint64_t)p->tile) / (double)(1ULL << wbits));
     const double m1 = share1 / (double)p->p1;
     const double m2 = (double)p->n_max / (double)p->n_seg;
     if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 cursors
+    const double ratio2 = segment_ratio(e);
     p->capw = piece_capacity(m1, 4.0);
-    p->cap2 = piece_capacity(m2, 64.0);
+    p->cap2 = piece_capacity(m2, ratio2);
     if (p->b3) {
         const double mA = (double)p->n_max / (double)(1ULL << (p->b1 + p->b2));
         if (mA * 2 + 1e6 >= 4.0e9) return false;
-        p->capA = piece_capacity(mA, 64.0);
+        p->capA = piece_capacity(mA, ratio2);
     }
     // piece stride = an odd multiple of 128 B past a 4-KiB boundary: the workgroups of repart read the same
     // tile of neighbouring pieces at the same time, and strides near a large power of two pile those reads
@@ -1362,10 +1542,10 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
 // 4.1-4.8 TB/s), the direct family ~54 ps per position (one random 64-B block per k-mer plus the global count
 // table); measured crossover near 175 bytes of set per position (2^40 bits against a 12.8 M-read batch: 23.6 vs
 // 14.7 Gk-mers/s).  Below a few million positions the fixed launch and sync costs of five kernels decide.
-inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases)
+inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases, int wbits = 0)
 {
-    const uint64_t filter_bytes = (1ULL << e->cfg.filter_log2_bits) / 8;
-    const int T = (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS;
+    const uint64_t filter_bytes = ((1ULL << e->cfg.filter_log2_bits) / 8) >> wbits;
+    const int T = set_segment_bits(e) - wbits;
     if (T < 1 || T > MAX_SEG_BITS) return false;
     return filter_bytes >= (32ULL << 20) && n_bases >= (4ULL << 20) && n_bases * 128 >= filter_bytes;
 }
@@ -1397,21 +1577,27 @@ inline void free_bufs(dk_engine *e, BucketBufs<R> &B)
     pool_free(e, B.extra_idx);
     pool_free(e, B.fine_cursor);
     pool_free(e, B.fine);
+    B = BucketBufs<R>();
 }
 
-// scan_part + repart (+ repart): afterwards B.rec / B.cursor2 hold every record of the batch grouped by segment,
-// except the records that did not fit, which are in B.ovf (Counters::n_ovf of them)
+// scan_part + repart (+ repart): afterwards B.rec / B.cursor2 hold every record of the batch (of the hash window
+// widx of 2^wbits, when wbits > 0) grouped by segment, except the records that did not fit, which are in B.ovf
+// (Counters::n_ovf of them).  need_scratch: a second segment-sized buffer for the absent lists (per-batch probe).
 template <bool WIDE>
 inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p,
-                                    BucketBufs<typename RecOf<WIDE>::type> &B)
+                                    BucketBufs<typename RecOf<WIDE>::type> &B, int wbits = 0, uint32_t widx = 0,
+                                    bool need_scratch = true)
 {
     using R = typename RecOf<WIDE>::type;
     const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
     const uint64_t lvl1_recs = (uint64_t)p.p1 * p.G * p.capw;
     const uint64_t n_coarse = p.b3 ? 1ULL << (p.b1 + p.b2) : 0;
     const uint64_t coarse_recs = n_coarse * p.capA;
-    DK_TRY(pool_alloc(e, std::max(seg_recs, lvl1_recs) * sizeof(R), (void **)&B.a));
-    DK_TRY(pool_alloc(e, std::max(seg_recs, coarse_recs) * sizeof(R), (void **)&B.b));
+    // two levels: a = level-1 pieces (then the absent lists), b = segments.  three: a = level 1, then segments; b = coarse (then absent lists)
+    const uint64_t a_recs = p.b3 ? std::max(seg_recs, lvl1_recs) : std::max(need_scratch ? seg_recs : 0, lvl1_recs);
+    const uint64_t b_recs = p.b3 ? std::max(need_scratch ? seg_recs : 0, coarse_recs) : seg_recs;
+    DK_TRY(pool_alloc(e, a_recs * sizeof(R), (void **)&B.a));
+    DK_TRY(pool_alloc(e, b_recs * sizeof(R), (void **)&B.b));
     const uint64_t n1 = (uint64_t)p.p1 * p.G;
     DK_TRY(pool_alloc(e, (n1 + 2 * p.n_seg + n_coarse) * 4, (void **)&B.cnt));
     B.cnt1 = B.cnt;
@@ -1433,15 +1619,16 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     sv.n_bwords = (r->n_bases + 31) / 32;
     sv.n_mwords = (r->n_bases + 63) / 64;
     const uint32_t n_tiles = (uint32_t)((r->n_bases + p.tile - 1) / p.tile);
-#define DK_SCAN_LAUNCH(TH, PT, W)                                                                                        \
-    scan_part_kernel<TH, PT, W, WIDE><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, \
-                                                                 p.b1, p.capw, B.a, B.cnt1, n_tiles, ovf, e->d_ctr)
+#define DK_SCAN_LAUNCH(TH, PT, W, WIN)                                                                                    \
+    scan_part_kernel<TH, PT, W, WIDE, WIN><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical,           \
+                                                                      e->cfg.seed, p.b1, p.capw, B.a, B.cnt1, n_tiles,    \
+                                                                      ovf, e->d_ctr, wbits, widx)
     // level 2: the level-1 pieces -> the segments' regions, or (three levels) -> 2^(b1+b2) coarse regions
 #define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
     do {                                                                                                  \
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                          \
-            B.a, B.cnt1, p.G, p.capw, tpp, p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                         \
+            B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
             p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr);                                                  \
     } while (0)
     // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
@@ -1449,10 +1636,11 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     do {                                                                                                  \
         const uint32_t tpp = (p.capA + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<dim3(tpp, 1u << (p.b1 + p.b2)), TH, 0, e->stream>>>(                 \
-            B.b, B.cursorA, 1u, p.capA, tpp, p.b1 + p.b2, p.b3, p.cap2, B.a, B.cursor2, ovf, e->d_ctr);    \
+            B.b, B.cursorA, 1u, p.capA, tpp, wbits + p.b1 + p.b2, p.b3, p.cap2, B.a, B.cursor2, ovf, e->d_ctr); \
     } while (0)
     if constexpr (WIDE) {
-        DK_SCAN_LAUNCH(512, 8, 4);
+        if (wbits) DK_SCAN_LAUNCH(512, 8, 4, true);
+        else DK_SCAN_LAUNCH(512, 8, 4, false);
         DK_HIP(e, hipGetLastError());
         stage_mark(e, "scan_part");
         DK_REPART_LAUNCH(512, 8, 8);
@@ -1462,19 +1650,23 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
             DK_REPART3_LAUNCH(512, 8, 8);
         }
     } else {
-        switch (p.variant) {
-        case 1: DK_SCAN_LAUNCH(1024, 8, 4); break;
-        case 2: DK_SCAN_LAUNCH(512, 16, 4); break;
-        case 3: DK_SCAN_LAUNCH(512, 8, 8); break;
-        case 4: DK_SCAN_LAUNCH(256, 16, 4); break;
-        case 5: DK_SCAN_LAUNCH(128, 16, 3); break;
-        case 6: DK_SCAN_LAUNCH(1024, 16, 4); break;
-        default: DK_SCAN_LAUNCH(1024, 8, 8); break;
+        if (wbits) {
+            if (p.variant == 6) DK_SCAN_LAUNCH(1024, 16, 4, true);
+            else DK_SCAN_LAUNCH(512, 16, 4, true);
+        } else {
+            switch (p.variant) {
+            case 1: DK_SCAN_LAUNCH(1024, 8, 4, false); break;
+            case 2: DK_SCAN_LAUNCH(512, 16, 4, false); break;
+            case 3: DK_SCAN_LAUNCH(512, 8, 8, false); break;
+            case 4: DK_SCAN_LAUNCH(256, 16, 4, false); break;
+            case 5: DK_SCAN_LAUNCH(128, 16, 3, false); break;
+            case 6: DK_SCAN_LAUNCH(1024, 16, 4, false); break;
+            default: DK_SCAN_LAUNCH(1024, 8, 8, false); break;
+            }
         }
         DK_HIP(e, hipGetLastError());
         stage_mark(e, "scan_part");
-        static const int rv = [] { const char *v = getenv("DK_REPART_VARIANT"); return v ? atoi(v) : 0; }();
-        if (rv == 1) DK_REPART_LAUNCH(1024, 16, 4);
+        if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
         else DK_REPART_LAUNCH(1024, 8, 8);
         if (p.b3) {
             DK_HIP(e, hipGetLastError());
@@ -1490,11 +1682,23 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     return DK_OK;
 }
 
+// copy the device counters to the host; the absent tallies of the segment kernels (Counters::shard) are folded
+// into n_absent on both sides, so every later copy sees one consistent number
 inline dk_status sync_counters(dk_engine *e, const char *what)
 {
     hipError_t h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
     if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
     if (h != hipSuccess) return fail(e, DK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(h));
+    unsigned long long sh = 0;
+    for (int i = 0; i < COUNTER_SHARDS; i++) sh += e->h_ctr->shard[i];
+    if (sh) {
+        e->h_ctr->n_absent += sh;
+        memset(e->h_ctr->shard, 0, sizeof e->h_ctr->shard);
+        h = hipMemcpyAsync(&e->d_ctr->n_absent, &e->h_ctr->n_absent, 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) h = hipMemsetAsync(e->d_ctr->shard, 0, sizeof e->h_ctr->shard, e->stream);
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);     // the copy reads h_ctr, which the caller goes on to edit
+        if (h != hipSuccess) return fail(e, DK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(h));
+    }
     if (e->h_ctr->n_overflow)
         return fail(e, DK_ERR_OVERFLOW, "bucket overflow (%llu records)", (unsigned long long)e->h_ctr->n_overflow);
     return DK_OK;
@@ -1509,7 +1713,7 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     BucketPlan p;
     if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
-    dk_status st = bucketed_partition<WIDE>(e, r, p, B);
+    dk_status st = bucketed_partition<WIDE>(e, r, p, B, 0, 0, false);
     if (st == DK_OK) {
         const PieceList<R> pl{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
         if (s->exact)
@@ -1534,10 +1738,95 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     return st;
 }
 
-inline uint64_t seg_count_mid_threshold()
+// the membership kernel of one batch over the n_seg segments from seg_base on (the set's kind and hash count pick the
+// instance); s == nullptr is only valid with ACC: every record is absent
+template <class R, bool ACC>
+inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &list, uint64_t n_seg, int T_full,
+                                   uint64_t seg_base, const MissOut<R> &mo)
 {
-    static const uint64_t v = [] { const char *e = getenv("DK_CNT_MID"); return e ? (uint64_t)atoll(e) : 3600ULL; }();
-    return v;
+    const int blk_shift = 64 - T_full - SEG_LOG2_BLOCKS;
+    if (s && s->exact)
+        seg_exact_probe_kernel<R, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, T_full, seg_base, mo, e->d_ctr);
+    else if (s && e->cfg.n_hashes == 4)
+        seg_probe_kernel<R, 4, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, 4, blk_shift, seg_base, mo, e->d_ctr);
+    else
+        seg_probe_kernel<R, 0, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
+            s ? s->d_words : nullptr, list, s ? (int)e->cfg.n_hashes : 0, blk_shift, seg_base, mo, e->d_ctr);
+    return hipGetLastError();
+}
+
+// Count the records of `list` unit by unit into res (seg_count): n_units units whose hashes share the top Tc bits
+// (unit_base + local index), n_absent records in all (sizes the table), extra_room more entries per region.
+// dry_first: first run the kernel without writes to learn how many entries pass min_count, and size the table from
+// that (an accumulator of a whole sample with min_count > 1 keeps a small fraction of its records).
+template <bool WIDE>
+inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename RecOf<WIDE>::type> &list, uint64_t n_units,
+                                      int Tc, uint64_t unit_base, uint64_t n_absent, uint64_t extra_room, uint32_t min_count,
+                                      bool dry_first, dk_result *res)
+{
+    if (!n_absent) return DK_OK;
+    const uint64_t per_seg = n_absent / n_units;
+    auto launch = [&](uint64_t region_cap, int dry) -> hipError_t {
+        if (per_seg >= (WIDE ? 3500u : 7000u)) {
+            // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
+            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 2);
+            seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+        } else if (per_seg >= (WIDE ? 1300u : (uint64_t)(e->opt.cnt_mid > 0 ? e->opt.cnt_mid : 3600))) {
+            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 6);
+            seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+        } else if (per_seg >= (WIDE ? 600u : 1200u)) {
+            // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each
+            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 12);
+            seg_count_kernel<256, 1024, 1024, WIDE><<<cgrid, 256, 0, e->stream>>>(
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+        } else {
+            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 32);
+            seg_count_kernel<128, 512, 256, WIDE><<<cgrid, 128, 0, e->stream>>>(
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+        }
+        return hipGetLastError();
+    };
+    // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the
+    // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
+    // overflow records may all sit in one segment, hence the extra room for them
+    const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, n_units);
+    uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536 + extra_room;
+    dk_status st = DK_OK;
+    if (dry_first) {
+        hipError_t h = launch(~0ULL, 1);
+        if (h != hipSuccess) return fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
+        stage_mark(e, "seg_count_dry");
+        DK_TRY(sync_counters(e, "bucketed count (sizing run)"));
+        region_cap = 1;
+        for (int j = 0; j < RESULT_REGIONS; j++) region_cap = std::max<uint64_t>(region_cap, e->h_ctr->region_fill[j]);
+        // the real run starts from clean tallies (same grid, same walk: every region receives exactly what was counted)
+        e->h_ctr->n_distinct = 0;
+        hipError_t h2 = hipMemsetAsync(e->d_ctr->region_fill, 0, sizeof e->h_ctr->region_fill, e->stream);
+        if (h2 == hipSuccess) h2 = hipMemsetAsync(&e->d_ctr->n_distinct, 0, 8, e->stream);
+        if (h2 != hipSuccess) return fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h2));
+    }
+    st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
+    if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
+    if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
+    if (st == DK_OK) {
+        hipError_t h = launch(region_cap, 0);
+        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
+        else stage_mark(e, "seg_count");
+    }
+    if (st == DK_OK) st = sync_counters(e, "bucketed count");
+    if (st == DK_OK) {
+        res->n_regions = RESULT_REGIONS;
+        res->region_cap = region_cap;
+        res->n = 0;
+        for (int j = 0; j < RESULT_REGIONS; j++) {
+            res->region_n[j] = e->h_ctr->region_fill[j];
+            res->n += res->region_n[j];
+        }
+        e->h_ctr->n_emitted = res->n;
+    }
+    return st;
 }
 
 template <bool WIDE>
@@ -1546,23 +1835,15 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     using R = typename RecOf<WIDE>::type;
     BucketPlan p;
     const uint64_t n_max = r->n_windows && r->n_windows < r->n_bases ? r->n_windows : r->n_bases;
-    if (!make_plan(e, r, &p, s ? 0 : count_segments_log2(n_max)))
+    if (!make_plan(e, r, &p, s ? 0 : count_segments_log2(e, n_max)))
         return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B);
     PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
-        if (s->exact)
-            seg_exact_probe_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, p.T, B.scratch, miss_cap, B.miss_cnt, e->d_ctr);
-        else if (e->cfg.n_hashes == 4)
-            seg_probe_kernel<R, 4><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, 4, 64 - p.T - SEG_LOG2_BLOCKS, B.scratch, miss_cap, B.miss_cnt, e->d_ctr);
-        else
-            seg_probe_kernel<R, 0><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, list, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS, B.scratch, miss_cap, B.miss_cnt, e->d_ctr);
-        hipError_t h = hipGetLastError();
+        const MissOut<R> mo{B.scratch, miss_cap, B.miss_cnt, 0, 0, OvfList<R>{nullptr, nullptr, 0}};
+        const hipError_t h = launch_seg_probe<R, false>(e, s, list, p.n_seg, p.T, 0, mo);
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
         else stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
         list = PieceList<R>{B.scratch, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
@@ -1601,7 +1882,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
             if (h == hipSuccess) {
                 ovf_probe_kernel<R><<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
                     s ? s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes,
-                    s && s->exact ? p.T : 0, Tc, B.ovf_miss, hist, e->d_ctr);
+                    s && s->exact ? p.T : 0, Tc, 0, B.ovf_miss, hist, e->d_ctr);
                 ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)n_units);
                 h = hipGetLastError();
             }
@@ -1614,7 +1895,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
             if (st == DK_OK && e->h_ctr->n_ovf_miss) {
                 const uint64_t n_om = e->h_ctr->n_ovf_miss;
                 ovf_scatter_kernel<R><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                    B.ovf_miss, n_om, Tc, off, fill, B.extra);
+                    B.ovf_miss, n_om, Tc, 0, off, fill, B.extra);
                 h = hipGetLastError();
                 if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow scatter failed: %s", hipGetErrorString(h));
                 list.extra = B.extra;
@@ -1672,52 +1953,67 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
             }
         }
     }
-    if (st == DK_OK && n_absent) {
-        // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the
-        // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
-        // overflow records may all sit in one segment, hence the extra room for them
-        const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, n_units);
-        const uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536 + e->h_ctr->n_ovf_miss;
-        st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
-        if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
-        if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
+    if (st == DK_OK)
+        st = bucketed_count_stage<WIDE>(e, list, n_units, Tc, 0, n_absent, e->h_ctr->n_ovf_miss, e->cfg.min_count, false, res);
+    free_bufs(e, B);
+    return st;
+}
+
+// ---- accumulator: one batch (dk_accum_add) ------------------------------------------------------------------
+template <class R>
+inline MissOut<R> accum_out(dk_engine *e, const dk_accum *a)
+{
+    return MissOut<R>{(R *)a->store, a->unit_cap, a->fill, a->u, 64 - a->T - a->u, OvfList<R>{(R *)a->ovf, a->d_novf, a->ovf_cap}};
+}
+inline int accum_unit_bits(const dk_accum *a) { return a->T + a->u; }
+inline uint64_t accum_unit_base(const dk_accum *a) { return (uint64_t)a->widx << (a->T - a->wbits + a->u); }
+
+// Partition the batch's records of the accumulator's hash window, test them against the set and append the absent
+// ones to the accumulator's units.  DK_ERR_OVERFLOW with nothing appended when the partition's overflow list
+// overflowed (the caller redoes the batch through the direct family); any other failure leaves the accumulator unusable.
+template <bool WIDE>
+inline dk_status bucketed_accum_add_t(dk_engine *e, dk_accum *a, const dk_reads *r, bool *appended)
+{
+    using R = typename RecOf<WIDE>::type;
+    *appended = false;
+    BucketPlan p;
+    if (!make_plan(e, r, &p, a->T, a->wbits)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
+    BucketBufs<R> B;
+    dk_status st = bucketed_partition<WIDE>(e, r, p, B, a->wbits, a->widx, false);
+    // nothing may be appended from a batch whose partition lost records: look before the membership kernel runs
+    if (st == DK_OK) st = sync_counters(e, "bucketed partition");
+    if (st != DK_OK) { free_bufs(e, B); return st; }
+    const PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
+    const MissOut<R> mo = accum_out<R>(e, a);
+    const uint64_t seg_base = (uint64_t)a->widx << (a->T - a->wbits);
+    *appended = true;
+    hipError_t h = launch_seg_probe<R, true>(e, a->s, list, p.n_seg, a->T, seg_base, mo);
+    if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
+    else stage_mark(e, a->s && a->s->exact ? "seg_exact_probe" : a->s ? "seg_probe" : "seg_append");
+    // overflow records of the partition (normally none): probe one by one, append the absent ones through global cursors
+    if (st == DK_OK && e->h_ctr->n_ovf) {
+        const uint64_t n_ovf = e->h_ctr->n_ovf;
+        st = pool_alloc(e, n_ovf * sizeof(R), (void **)&B.ovf_miss);
         if (st == DK_OK) {
-            const uint64_t per_seg = n_absent / n_units;
-            if (per_seg >= (WIDE ? 3500u : 7000u)) {
-                // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 2);
-                seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
-                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
-            } else if (per_seg >= (WIDE ? 1300u : seg_count_mid_threshold())) {
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 6);
-                seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
-                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
-            } else if (per_seg >= (WIDE ? 600u : 1200u)) {
-                // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 12);
-                seg_count_kernel<256, 1024, 1024, WIDE><<<cgrid, 256, 0, e->stream>>>(
-                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
-            } else {
-                const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 32);
-                seg_count_kernel<128, 512, 256, WIDE><<<cgrid, 128, 0, e->stream>>>(
-                    list, n_units, Tc, e->cfg.seed, e->cfg.min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr);
-            }
-            hipError_t h = hipGetLastError();
-            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
-            else stage_mark(e, "seg_count");
+            const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+            ovf_probe_kernel<R><<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                a->s ? a->s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes,
+                a->s && a->s->exact ? a->T : 0, 1, 0, B.ovf_miss, nullptr, e->d_ctr);
+            h = hipGetLastError();
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow probe failed: %s", hipGetErrorString(h));
         }
-        if (st == DK_OK) st = sync_counters(e, "bucketed count");
-        if (st == DK_OK) {
-            res->n_regions = RESULT_REGIONS;
-            res->region_cap = region_cap;
-            res->n = 0;
-            for (int j = 0; j < RESULT_REGIONS; j++) {
-                res->region_n[j] = e->h_ctr->region_fill[j];
-                res->n += res->region_n[j];
-            }
-            e->h_ctr->n_emitted = res->n;
+        if (st == DK_OK) st = sync_counters(e, "overflow probe");
+        if (st == DK_OK && e->h_ctr->n_ovf_miss) {
+            const uint64_t n_om = e->h_ctr->n_ovf_miss;
+            acc_append_kernel<R><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                B.ovf_miss, n_om, accum_unit_bits(a), accum_unit_base(a), mo, e->d_ctr);
+            h = hipGetLastError();
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow append failed: %s", hipGetErrorString(h));
+            else stage_mark(e, "ovf_append");
         }
     }
+    if (st == DK_OK) st = sync_counters(e, "bucketed accumulate");
+    if (st == DK_OK) e->h_ctr->n_absent += e->h_ctr->n_ovf_miss;
     free_bufs(e, B);
     return st;
 }

@@ -13,6 +13,7 @@ namespace dk {
 constexpr int DIRECT_BLOCK = 256;
 constexpr uint32_t SLOT_EMPTY = 0xFFFFFFFFu;
 constexpr int RESULT_REGIONS = 32;      // output regions of the bucketed count kernel (one fill counter each)
+constexpr int COUNTER_SHARDS = 32;      // per-workgroup tallies are spread over this many words (one word takes ~10^8 atomics/s)
 
 struct StreamView {
     const uint64_t *bases;
@@ -40,8 +41,10 @@ struct Counters {               // device-side statistics of one operation
     unsigned long long n_ovf;       // bucketed: records appended to the overflow list
     unsigned long long n_ovf_miss;  // bucketed: overflow records absent from the filter
     unsigned long long n_set_full;  // exact set: keys that found no free slot in their segment
+    unsigned long long n_in_window; // windowed scan (dk_accum_add): valid windows whose hash lies in the window
     unsigned long long dbg[8];      // DK_STAMPS diagnostic builds only: per-phase cycle sums
     unsigned long long region_fill[32];   // bucketed seg_count: entries written to each output region
+    unsigned long long shard[32];         // bucketed seg_probe: absent records, tallied per workgroup (folded into n_absent on the host)
 };
 
 // ---- ASCII -> packed stream ------------------------------------------------------------------
@@ -357,22 +360,32 @@ count_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__rest
     }
 }
 
-// merge of (k-mer, count) tables: same table as count_insert, the entry's count is added
-template <bool WIDE>
+// merge of (k-mer, count) tables: same table as count_insert, the entry's count is added.  The table is built
+// for one hash range at a time (pass q of 2^pbits: the candidates whose hash starts with the bits of q), which
+// bounds its size, and slots hold 64-bit candidate indices once there are 2^32 - 1 candidates or more.
+template <class IdxT> struct SlotOf { static constexpr IdxT EMPTY = (IdxT)~(IdxT)0; };
+
+template <bool WIDE, class IdxT>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 merge_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,
-                    const uint32_t *__restrict__ cand_cnt, uint64_t n_cand, uint32_t *slots, uint32_t *counts,
-                    int log2_cap, uint64_t seed)
+                    const uint32_t *__restrict__ cand_cnt, uint64_t n_cand, IdxT *slots, uint32_t *counts,
+                    int log2_cap, uint64_t seed, int pbits, uint32_t q)
 {
+    constexpr IdxT EMPTY = SlotOf<IdxT>::EMPTY;
     const uint64_t cap_mask = (1ULL << log2_cap) - 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += stride) {
         Kmer km{WIDE ? cand_hi[i] : 0, cand_lo[i]};
-        uint64_t s = hash_kmer<WIDE>(km, seed) >> (64 - log2_cap);
+        const uint64_t h = hash_kmer<WIDE>(km, seed);
+        if (pbits && (uint32_t)(h >> (64 - pbits)) != q) continue;
+        uint64_t s = ((h << pbits) >> (64 - log2_cap)) & cap_mask;
         for (;;) {
-            uint32_t cur = slots[s];
-            if (cur == SLOT_EMPTY) cur = atomicCAS(&slots[s], SLOT_EMPTY, (uint32_t)i);
-            if (cur == SLOT_EMPTY) break;                       // claimed
+            IdxT cur = slots[s];
+            if (cur == EMPTY) {
+                if constexpr (sizeof(IdxT) == 8) cur = (IdxT)atomicCAS((unsigned long long *)&slots[s], (unsigned long long)EMPTY, (unsigned long long)i);
+                else cur = (IdxT)atomicCAS((unsigned int *)&slots[s], (unsigned int)EMPTY, (unsigned int)i);
+            }
+            if (cur == EMPTY) break;                            // claimed
             if (cand_lo[cur] == km.lo && (!WIDE || cand_hi[cur] == km.hi)) break;
             s = (s + 1) & cap_mask;
         }
@@ -388,24 +401,26 @@ merge_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__rest
     }
 }
 
-template <bool WIDE>
+template <bool WIDE, class IdxT = uint32_t>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 count_emit_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,
-                  const uint32_t *__restrict__ slots, const uint32_t *__restrict__ counts,
+                  const IdxT *__restrict__ slots, const uint32_t *__restrict__ counts,
                   uint64_t cap, uint32_t min_count, Counters *ctr,
                   uint64_t *__restrict__ out_lo, uint64_t *__restrict__ out_hi,
                   uint32_t *__restrict__ out_cnt)
 {
+    constexpr IdxT EMPTY = SlotOf<IdxT>::EMPTY;
     __shared__ BlockAppend<WIDE, true> app;
     app.init();
     uint64_t n_distinct = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n_round = (cap + blockDim.x - 1) / blockDim.x * blockDim.x;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_round; s += stride) {
-        uint32_t idx = SLOT_EMPTY, c = 0;
+        IdxT idx = EMPTY;
+        uint32_t c = 0;
         if (s < cap) idx = slots[s];
-        if (idx != SLOT_EMPTY) { c = counts[s]; n_distinct++; }
-        const bool emit = idx != SLOT_EMPTY && c >= min_count;
+        if (idx != EMPTY) { c = counts[s]; n_distinct++; }
+        const bool emit = idx != EMPTY && c >= min_count;
         uint64_t vlo = 0, vhi = 0;
         if (emit) { vlo = cand_lo[idx]; if (WIDE) vhi = cand_hi[idx]; }
         app.push(emit, vlo, vhi, c);

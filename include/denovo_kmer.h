@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DK_ABI_VERSION 1
+#define DK_ABI_VERSION 2
 
 typedef int32_t dk_status;
 enum {
@@ -67,6 +67,8 @@ typedef struct dk_engine dk_engine;
 typedef struct dk_reads dk_reads;     /* device-resident packed read batch */
 typedef struct dk_set dk_set;         /* KmerSet: parent blocked-Bloom filter resident in HBM */
 typedef struct dk_result dk_result;   /* k-mer -> count table (child-only set, or KmerCounter output) */
+typedef struct dk_accum dk_accum;     /* child-only k-mer occurrences of many batches, counted once at the end */
+typedef struct dk_comm dk_comm;       /* RCCL communicator of an engine (one rank per GPU) */
 
 typedef struct dk_config {
     uint64_t struct_size;        /* = sizeof(dk_config); versions the struct */
@@ -122,6 +124,15 @@ const char *dk_last_error(const dk_engine *e);          /* e may be NULL: last c
 dk_status   dk_engine_synchronize(dk_engine *e);
 dk_status   dk_engine_timings(const dk_engine *e, dk_timings *out);   /* of the last insert/probe/count */
 dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
+/* Run-time options, validated (unknown name or value out of range: DK_ERR_INVALID_ARG); 0 restores the default.
+ *   "multiplicity_hint"  expected copies of one k-mer inside ONE batch (~ the batch's coverage of the genome).
+ *                        Capacity planning of the bucket regions only -- results are exact for any value, a low one
+ *                        makes the overflow path likelier.  Default: up to 64 copies (a whole 30-60x sample per batch);
+ *                        set ~2 for one of the ~40 batches of a whole-genome sample: the workspace shrinks ~2x.
+ *   test hooks, which force a kernel geometry on inputs too small to select it:
+ *   "scan_variant" 1..6, "repart_variant" 0..1, "force_l3" 0..1, "b1_up" -4..4, "count_seg" >= 64, "cnt_mid" >= 1,
+ *   "sweep_variant" 0..2 */
+dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
 
 /* ---- read batches (replaces: the &[u8] read sequences handed to kmer.rs by the BAM loop) --- */
 /* ASCII reads, concatenated, offsets[n_reads+1]; packed on the GPU */
@@ -200,6 +211,36 @@ dk_status dk_result_device_view(const dk_result *res, const void **d_kmers_lo, c
 dk_status dk_result_merge(dk_engine *e, const dk_result *const *results, uint32_t n_results,
                           uint32_t min_count, dk_result **out, dk_stats *stats);
 void      dk_result_destroy(dk_result *res);
+
+/* ---- child-only accumulator: a sample that arrives in many batches (replaces: the KmerCounter that the child
+ * loop of counter.rs keeps across the whole BAM) -----------------------------------------------------------------
+ * dk_probe returns the table of ONE batch; summing per-batch tables does not scale to a whole genome (a 30x child
+ * leaves ~2 x 10^10 absent k-mer occurrences, nearly all distinct).  An accumulator keeps the absent occurrences
+ * themselves -- 8-byte bucket records (16 for k > 32) grouped by hash prefix -- across any number of dk_accum_add
+ * calls and counts each group once in dk_accum_finish, so counts and the min_count threshold are exact over the
+ * whole sample.  When the records of the whole hash space do not fit beside the set, the sample is streamed
+ * window_count times (a power of two): pass w keeps only the k-mers whose hash falls into the w-th of window_count
+ * equal ranges; every pass touches 1/window_count of the set and of the partition workspace, and the union of the
+ * passes' tables is the whole result (the ranges are disjoint).
+ *   capacity_records  expected number of absent occurrences per pass (slack for the spread between groups is added
+ *                     inside: the store takes ~1.3 x 8 bytes x capacity); occurrences beyond a group's room go to
+ *                     an overflow list of capacity/64 entries, and DK_ERR_OVERFLOW is returned once that is full
+ *                     (the accumulator is then unusable until dk_accum_reset; use more windows or a larger capacity)
+ *   s == NULL         every k-mer counts (KmerCounter over a sample in batches) */
+dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32_t window_count,
+                          uint64_t capacity_records, dk_accum **out);
+/* probe batch r against the set and append its absent occurrences inside the window; stats: n_reads, n_bases,
+ * n_windows, n_valid (all valid windows of the batch) and n_absent (appended by this call) */
+dk_status dk_accum_add(dk_accum *a, const dk_reads *r, dk_stats *stats);
+/* (k-mer, count) of everything accumulated, counts >= min_count; stats: totals over all batches + n_distinct,
+ * n_emitted.  The accumulator keeps its content (finish may be called again with another threshold). */
+dk_status dk_accum_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_stats *stats);
+/* empty the accumulator and move it to another window (same window_count): the next pass over the sample */
+dk_status dk_accum_reset(dk_accum *a, uint32_t window_index);
+dk_status dk_accum_stats(const dk_accum *a, dk_stats *out);     /* totals so far */
+/* bytes of device memory the accumulator holds */
+dk_status dk_accum_device_bytes(const dk_accum *a, uint64_t *n_bytes);
+void      dk_accum_destroy(dk_accum *a);
 
 #ifdef __cplusplus
 }

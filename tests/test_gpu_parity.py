@@ -111,7 +111,7 @@ def test_trio_parity(rng, mode, k, log2_bits, nh, canonical):
         assert_result_equals(res, km, cn)
         assert_stats(res.stats, pst, ["n_reads", "n_windows", "n_valid", "n_absent", "n_distinct"])
         assert res.stats["n_emitted"] == len(km)
-        assert ks.popcount() == int(np.unpackbits(f.view(np.uint8)).sum())
+        assert ks.popcount() == int(np.bitwise_count(f).sum())
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -541,12 +541,17 @@ def test_full_size_configs1_properties():
 # ---- multi-batch samples: device-side merge of per-batch tables ----------------------------------------
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("k", [31, 45])
-def test_result_merge_equals_whole_sample(rng, mode, k):
+@pytest.mark.parametrize("k,merge_options", [(31, {}), (45, {}), (31, {"merge_pass_bits": 3}), (45, {"merge_pass_bits": 2, "merge_idx64": 1}),
+                                             (31, {"merge_idx64": 1})])
+def test_result_merge_equals_whole_sample(rng, mode, k, merge_options):
+    """merge_pass_bits / merge_idx64 force the hash-range passes and the 64-bit candidate indices that tables of
+    2^32 entries and more take"""
     d = dk()
     parents, child = related_trio(rng, genome_len=4000, n_reads=150, read_len=120)
     child = child + child[:40] + child[10:30]
     with make_engine(mode, k=k, filter_log2_bits=22, n_hashes=4, seed=77, min_count=1) as eng:
+        for name, value in merge_options.items():
+            eng.set_option(name, value)
         ks = d.KmerSet(eng)
         ks.insert_sequences(parents)
         kc = d.KmerCounter(eng)
@@ -608,44 +613,60 @@ def test_every_seg_count_geometry_counts_exactly(rng, n_reads, k):
         assert res.stats["n_distinct"] == st["n_distinct"] and int(cn.max()) >= 2
 
 
-_VARIANT_SCRIPT = r"""
-import sys
-sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
-import numpy as np
-import denovo_kmer_amd as d
-from conftest import related_trio
-from oracle import orc
-rng = np.random.default_rng(4242)
-parents, child = related_trio(rng, genome_len=30000, n_reads=900, read_len=140)
-for k in (31, 45):
-    pseq, poff = orc.concat_reads(parents); cseq, coff = orc.concat_reads(child)
-    f = orc.new_filter(24)
-    orc.bloom_insert(f, 24, 4, 7, k, True, pseq, poff)
-    km, cn, st = orc.bloom_probe(f, 24, 4, 7, k, True, cseq, coff)
-    with d.Engine(k=k, filter_log2_bits=24, n_hashes=4, seed=7, mode="bucketed") as eng:
-        ks = d.KmerSet(eng); ks.insert_sequences(parents)
-        assert np.array_equal(ks.to_host(), f)
-        res = d.KmerCounter(eng).child_only(d.ReadBatch.from_sequences(eng, child), ks)
-        names = [n for n, _ in eng.timings()["stages"]]
-        assert names[:2] == ["scan_part", "repart"] and "overflow_redo" not in names, names
-        hi, lo, cnt = res.to_host()
-        assert np.array_equal(lo, km["lo"]) and np.array_equal(hi, km["hi"]) and np.array_equal(cnt, cn)
-print("variant ok")
-"""
+def _forced_geometry_trio(options, expect_stages):
+    """small related trio through the bucketed family with kernel geometries forced by engine options
+    (dk_engine_set_option test hooks), checked against the oracle"""
+    d = dk()
+    rng = np.random.default_rng(4242)
+    parents, child = related_trio(rng, genome_len=30000, n_reads=900, read_len=140)
+    for k in (31, 45):
+        f, ist, km, cn, pst = oracle_trio(parents, child, k, 24, 4, 7)
+        with d.Engine(k=k, filter_log2_bits=24, n_hashes=4, seed=7, mode="bucketed") as eng:
+            for name, value in options.items():
+                eng.set_option(name, value)
+            ks = d.KmerSet(eng)
+            ks.insert_sequences(parents)
+            assert np.array_equal(ks.to_host(), f)
+            res = d.KmerCounter(eng).child_only(d.ReadBatch.from_sequences(eng, child), ks)
+            names = [n for n, _ in eng.timings()["stages"]]
+            assert names[:len(expect_stages)] == expect_stages and "overflow_redo" not in names, names
+            assert_result_equals(res, km, cn)
+            assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
 
 
-@pytest.mark.parametrize("scan_variant,repart_variant", [(6, 0), (1, 0), (3, 1), (4, 0), (5, 0)])
+@pytest.mark.parametrize("scan_variant,repart_variant", [(6, 0), (1, 0), (3, 1), (4, 0), (5, 0), (2, 0)])
 def test_scan_part_tile_shapes_agree_with_the_oracle(scan_variant, repart_variant):
     """The scan_part geometry is chosen from the number of segments (2 below 2^16 segments, 6 from there on);
-    the environment switches force each compiled shape on a small input so that all of them are checked
-    (the switch is read once per process, hence the subprocess)."""
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = dict(os.environ, DK_SCAN_VARIANT=str(scan_variant), DK_REPART_VARIANT=str(repart_variant))
-    script = _VARIANT_SCRIPT.format(root=ROOT, tests=os.path.dirname(__file__))
-    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+    the engine options force each compiled shape on a small input so that all of them are checked"""
+    _forced_geometry_trio({"scan_variant": scan_variant, "repart_variant": repart_variant}, ["scan_part", "repart"])
+
+
+def test_forced_scan_shape_with_fewer_threads_than_bins():
+    """variants 4 / 5 have 256 / 128 threads; with more level-1 bins than threads the plan moves bits to level 2
+    (2^33 bits = 2^14 segments: b1_up pushes the level-1 split to 9 bits = 512 bins)"""
+    d = dk()
+    rng = np.random.default_rng(7)
+    parents, child = related_trio(rng, genome_len=20000, n_reads=500, read_len=120)
+    f, ist, km, cn, pst = oracle_trio(parents, child, 31, 33, 4, 7)
+    for variant in (4, 5):
+        with d.Engine(k=31, filter_log2_bits=33, n_hashes=4, seed=7, mode="bucketed") as eng:
+            eng.set_option("scan_variant", variant)
+            eng.set_option("b1_up", 4)
+            ks, _, res = gpu_trio(eng, parents, child)
+            assert ks.popcount() == int(np.bitwise_count(f).sum())
+            assert_result_equals(res, km, cn)
+            ks.close()
+
+
+def test_engine_options_are_validated():
+    d = dk()
+    with d.Engine(k=31, filter_log2_bits=24) as eng:
+        for name, value in (("scan_variant", 7), ("scan_variant", -1), ("no_such_option", 1), ("force_l3", 2), ("count_seg", 5)):
+            with pytest.raises(d.DkError) as ei:
+                eng.set_option(name, value)
+            assert ei.value.status == 1
+        eng.set_option("multiplicity_hint", 2)
+        eng.set_option("scan_variant", 0)
 
 
 # ---- kmer.rs stand-in: per-position canonical k-mers and hashes (dk_reads_kmers) -----------------------
@@ -704,18 +725,9 @@ def test_per_position_kmers_match_the_oracle(rng, k, canonical):
 # ---- three partition levels: filters above 2^37 bits (2^19 segments and more) --------------------------
 
 def test_three_level_partition_forced_on_small_inputs():
-    """DK_FORCE_L3 sends every geometry with at least 8 segments through scan_part -> repart -> repart3 (the path
-    that 2^38-bit and larger filters take), so the oracle can check it at small sizes (subprocess: the switch
-    is read once per process)."""
-    import subprocess
-    import sys
-    from conftest import ROOT
-    script = _VARIANT_SCRIPT.format(root=ROOT, tests=os.path.dirname(__file__)).replace(
-        'assert names[:2] == ["scan_part", "repart"]', 'assert names[:3] == ["scan_part", "repart", "repart3"]')
-    assert "repart3" in script
-    env = dict(os.environ, DK_FORCE_L3="1")
-    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+    """force_l3 sends every geometry with at least 8 segments through scan_part -> repart -> repart3 (the path
+    that 2^38-bit and larger filters take), so the oracle can check it at small sizes"""
+    _forced_geometry_trio({"force_l3": 1}, ["scan_part", "repart", "repart3"])
 
 
 @pytest.mark.parametrize("set_kind", ["bloom", "exact"])
