@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path: Gk-mers/s, child reads vs parent Bloom, k=31.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload wgs|chr20|ont]
 
-A "step" is one membership pass of the hot path over one resident batch of synthetic child reads
-(BASELINE.json configs[1]: k=31, chr20-scale 30x trio of synthetic 150 bp reads = 12.8 M reads per
-sample per GPU) against the parent filter resident in HBM: k-mer extraction, canonicalisation,
-hashing, filter probe, and counting of the child-only k-mers into the output table.  Inputs are in
-HBM before the timed region.  The parent build (insert of both parents, and for N > 1 the
-OR-all-reduce of the filter over RCCL) is run once before the timed steps and reported in the same
-JSON line under "parent_build"; it is not part of `value` (the metric is the probe pass).
+Workloads (BASELINE.json `configs`):
+  wgs   (default) configs[2]: k=31, full 30x whole-genome trio, ~1.2 B synthetic 150-bp reads per sample on one
+        MI355X.  The parents are inserted batch by batch into a 2^39-bit (64 GiB) Bloom filter resident in HBM
+        (reported under "parent_build"); the child is streamed in batches through dk_accum_add, which keeps the
+        absent k-mer occurrences on the GPU so that counts and min_count are exact over the whole sample.  The
+        occurrences of the whole hash space do not fit beside the filter, so the child is streamed in
+        `hash_windows` passes, each covering 1/hash_windows of the hash space (and of the filter).
+        A "step" = one child batch through one pass; it completes 1/hash_windows of the batch's membership work,
+        so `value` counts n_windows / hash_windows per step.  The K timed steps end with the counting of what they
+        accumulated (dk_accum_finish) inside the timed region.  After the timed steps the whole child is run end
+        to end (all passes, all batches, finish) and reported under "end_to_end".
+  chr20 configs[1]: k=31, chr20-scale 30x trio = 12.8 M reads per sample per GPU, 2^34-bit filter; a step is one
+        dk_probe call over the resident child batch (round 1's headline).
+  ont   configs[4]: k=51, 10-kb reads with 5 % errors, 192 k reads per sample, 2^35-bit filter; step as chr20.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns 12.8 M
-reads of each sample of a genome N times larger, builds a partial filter, the partials are
-OR-all-reduced, and each rank probes its own child shard with no collective in the timed step.
+Inputs are resident in HBM before the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU):
+every rank owns 1/N of the reads of each sample (wgs) or its own 12.8 M reads of an N times larger genome (chr20,
+ont), builds a partial filter, the partials are OR-all-reduced (RCCL), and each rank probes its own child shard.
 """
 import argparse
 import json
@@ -26,33 +33,92 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+XGMI_LINK_GBS = 153.0          # per link, 7 links per GPU
+
+WORKLOADS = {
+    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=24_000_000, parent_batch=48_000_000, log2_bits=39, err=5e-3,
+                min_count=2, windows=2, cfg="configs[2]"),
+    "chr20": dict(k=31, read_len=150, reads=12_800_000, batch=12_800_000, parent_batch=12_800_000, log2_bits=34, err=5e-3,
+                  min_count=1, windows=1, cfg="configs[1]"),
+    "ont": dict(k=51, read_len=10_000, reads=192_000, batch=192_000, parent_batch=192_000, log2_bits=35, err=5e-2, min_count=1,
+                windows=1, cfg="configs[4]"),
+}
 
 
-def stage_algorithmic_bytes(stage, st, filter_bytes, read_len, k, geom=None):
+def stage_algorithmic_bytes(stage, st, filter_bytes, rec_bytes, windows=1):
     """Algorithmic HBM bytes one launch of `stage` must move.
-    st = dk_stats of the pass (n_bases, n_windows, n_valid, n_absent, n_distinct)."""
-    nb, nv, na, nd = st["n_bases"], st["n_valid"], st["n_absent"], st["n_distinct"]
+    st: n_bases, n_valid (all valid windows), n_absent (absent ones inside the hash window), n_distinct, n_emitted;
+    windows: hash windows of the pass (records, filter share and absent records are 1/windows of the batch's)."""
+    nb, na = st["n_bases"], st["n_absent"]
+    nv = st["n_valid"] / windows                            # records of this pass
+    nd, ne = st.get("n_distinct", 0), st.get("n_emitted", 0)
+    fb = filter_bytes / windows
+    R = float(rec_bytes)
     stream = nb * 3 / 8.0                                   # 2-bit bases + 1-bit mask
     table = {
         # direct family
-        "probe_direct": stream + 64.0 * nv + 8.0 * na,     # one 64-B filter block per k-mer, absent k-mers appended
+        "probe_direct": stream + 64.0 * nv + R * na,       # one 64-B filter block per k-mer, absent k-mers appended
         "insert_direct": stream + 128.0 * nv,              # block fetched and written back
-        "count_insert": 8.0 * na + 8.0 * na,               # candidate read + slot/count update
-        "count_emit": 12.0 * nd,
-        # bucketed family (records are 8-byte hashes)
-        "scan_part": stream + 8.0 * nv,                    # read stream, write one record per valid k-mer
-        "repart": 16.0 * nv,                               # read + write every record once
-        "seg_probe": 8.0 * nv + filter_bytes + 8.0 * na,   # records + one sweep of the filter + absent records out
-        "seg_insert": 8.0 * nv + 2.0 * filter_bytes,       # records + filter read and written back
-        "seg_count": 8.0 * na + 12.0 * nd,                 # absent records in, (k-mer, count) out
+        "count_insert": 2 * R * na,                         # candidate read + slot/count update
+        "count_emit": (R + 4) * nd,
+        # bucketed family (records: 8-byte hashes, 16 bytes for k > 32)
+        "scan_part": stream + R * nv,                       # read stream, write one record per k-mer of the window
+        "repart": 2 * R * nv,                               # read + write every record once
+        "repart3": 2 * R * nv,
+        "seg_probe": R * nv + fb + R * na,                  # records + one sweep of the filter share + absent records out
+        "seg_insert": R * nv + 2.0 * fb,                    # records + filter read and written back
+        "seg_count": R * na + (R + 4) * ne,                 # absent records in, (k-mer, count) out
+        "seg_count_dry": R * na,                            # sizing run of a min_count > 1 finish: records in, nothing out
+        "count_split": 2 * R * na,
         # exact set (--set-kind exact): the segments are hash tables, swept exactly like the filter
-        "seg_exact_probe": 8.0 * nv + filter_bytes + 8.0 * na,
-        "seg_exact_insert": 8.0 * nv + 2.0 * filter_bytes,
+        "seg_exact_probe": R * nv + fb + R * na,
+        "seg_exact_insert": R * nv + 2.0 * fb,
     }
     return table.get(stage)
 
 
-def cpu_baseline(dk, eng, kset, gcfg, args, sample_reads):
+def roofline_of(stage_ms, stage_bytes, traffic_by_kernel, traffic_source):
+    """roofline object of the pass: the dominant kernel on top, every stage under "stages", the pass total"""
+    stages = {}
+    for name, ms in stage_ms.items():
+        b = stage_bytes.get(name)
+        gbs = b / (ms * 1e-3) / 1e9 if b and ms > 0 else None
+        stages[name] = {"algorithmic_bytes": b, "ms": ms, "achieved": gbs,
+                        "frac": gbs / HBM_PEAK_GBS if gbs else None}
+    timed = {n: v for n, v in stages.items() if v["achieved"]}
+    dom = max(timed, key=lambda n: timed[n]["ms"]) if timed else None
+    tot_b = sum(v["algorithmic_bytes"] for v in timed.values())
+    tot_ms = sum(v["ms"] for v in timed.values())
+    out = {"bound": "hbm", "kernel": dom, "achieved": timed[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": timed[dom]["frac"] if dom else None,
+           "traffic": (traffic_by_kernel or {}).get(dom), "traffic_source": traffic_source,
+           "algorithmic_bytes_per_launch": timed[dom]["algorithmic_bytes"] if dom else None,
+           "kernel_ms": timed[dom]["ms"] if dom else None,
+           "stages": stages,
+           "pass": {"algorithmic_bytes": tot_b, "ms": tot_ms, "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
+                    "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tot_ms else None}}
+    return out
+
+
+def committed_traffic(workload, reads, log2_bits, world):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: FETCH_SIZE x2 gfx950 correction +
+    WRITE_SIZE, separate --pmc runs by tools/profile_round.sh), for the same workload only.  Static, not measured
+    in this run: the JSON says so in roofline.traffic_source."""
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(prof):
+        return None, None
+    try:
+        tj = json.load(open(prof))
+        entry = tj.get("workloads", {}).get(workload) or (tj if workload == "chr20" else None)
+        if entry and entry.get("reads") == reads and entry.get("log2_bits") == log2_bits:
+            return ({k: v.get("hbm_bytes_per_launch") for k, v in entry.get("kernels", {}).items()},
+                    "profiles/traffic.json (static: committed rocprofv3 --pmc passes of this workload, not this run)")
+    except Exception:
+        pass
+    return None, None
+
+
+def cpu_baseline(dk, eng, kset, gcfg, args, wl, sample_reads):
     """Time the CPU oracle ("port": the build's C restatement, OpenMP over reads on the host cores
     this process may use) on a bounded sample of the same child workload against the same filter,
     and cross-check the GPU on that sample."""
@@ -61,22 +127,37 @@ def cpu_baseline(dk, eng, kset, gcfg, args, sample_reads):
     filt = kset.to_host()
     sb = dk.ReadBatch.synth(eng, gcfg, 2, 0, sample_reads)
     bases, mask, _ = sb.download()
-    seq, off = orc.unpack_fixed(bases, mask, sample_reads, args.read_len)
+    seq, off = orc.unpack_fixed(bases, mask, sample_reads, wl["read_len"])
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # a one-GPU box grants this job a 16-core CPU share whatever the affinity mask says
     cores = max(1, min(cores, args.cpu_threads if args.cpu_threads > 0 else 16))
     t0 = time.perf_counter()
-    km, cn, st = orc.bloom_probe(filt, args.log2_bits, args.n_hashes, args.seed, args.k, True, seq, off, n_threads=cores)
+    km, cn, st = orc.bloom_probe(filt, args.log2_bits, args.n_hashes, args.seed, wl["k"], True, seq, off,
+                                 min_count=1, n_threads=cores)
     dt = time.perf_counter() - t0
+    t_probe, t_sort, t_merge = orc.last_phase_seconds()
     res = dk.KmerCounter(eng).child_only(sb, kset)
     hi, lo, cnt = res.to_host()
     ok = bool(np.array_equal(lo, km["lo"]) and np.array_equal(hi, km["hi"]) and np.array_equal(cnt, cn))
     res.close()
     sb.close()
-    return {"value": st["n_windows"] / dt / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample_reads} child reads of the same workload ({st['n_windows']} windows, "
-                      f"{dt:.1f} s), oracle/dk_oracle.c with {cores} OpenMP thread(s), same {len(filt) * 8 >> 20} MiB filter",
+    del filt
+    return {"value": st["n_windows"] / t_probe / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample_reads} child reads of the same workload ({st['n_windows']} windows), oracle/dk_oracle.c with "
+                      f"{cores} OpenMP thread(s) against the same {kset.n_bytes >> 20} MiB filter; value = windows / {t_probe:.1f} s "
+                      f"of extraction + hashing + filter probe (parallel); the oracle's exact counting of the absent k-mers took "
+                      f"{t_sort:.1f} s (parallel sort) + {t_merge:.1f} s (serial merge) more, {dt:.1f} s for the whole call",
+            "probe_seconds": t_probe, "sort_seconds": t_sort, "merge_seconds": t_merge, "whole_call_seconds": dt,
+            "value_including_counting": st["n_windows"] / dt / 1e9,
             "gpu_matches_oracle_on_sample": ok}
+
+
+T_START = time.perf_counter()
+
+
+def progress(msg):
+    """phase marks on stderr (a full-genome run is silent for minutes otherwise)"""
+    print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -84,32 +165,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--reads", type=int, default=12_800_000, help="reads per sample per GPU")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--genome", type=int, default=64 << 20, help="genome length per GPU (bases)")
-    ap.add_argument("--log2-bits", type=int, default=0, help="filter size; 0 = 34 + ceil(log2(gpus))")
+    ap.add_argument("--workload", default="wgs", choices=sorted(WORKLOADS))
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--reads", type=int, default=0, help="reads per sample (wgs: of the whole job; chr20/ont: per GPU)")
+    ap.add_argument("--batch", type=int, default=0, help="child reads per batch (one dk_accum_add / dk_probe call)")
+    ap.add_argument("--parent-batch", type=int, default=0, help="parent reads per batch (one dk_set_insert call)")
+    ap.add_argument("--log2-bits", type=int, default=0, help="filter size; 0 = the workload's (chr20/ont: + ceil(log2(gpus)))")
+    ap.add_argument("--windows", type=int, default=0, help="wgs: hash-window passes over the child")
+    ap.add_argument("--min-count", type=int, default=0)
     ap.add_argument("--n-hashes", type=int, default=4)
     ap.add_argument("--seed", type=int, default=20260313)
     ap.add_argument("--mode", default="auto", choices=["auto", "direct", "bucketed"])
     ap.add_argument("--set-kind", default="bloom", choices=["bloom", "exact"],
-                    help="bloom: the headline metric's parent Bloom filter; exact: exact parent set (side measurement, "
-                         "--log2-bits then defaults to 36 + ceil(log2(gpus)))")
-    ap.add_argument("--cpu-sample-reads", type=int, default=6_000_000)
+                    help="bloom: the headline metric's parent Bloom filter; exact: exact parent set (side measurement, chr20 only)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline; 0 = min(cores this process may use, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="wgs: skip the full child run after the timed steps")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
     import denovo_kmer_amd as dk
-    from denovo_kmer_amd.dist import local_reduce_fn, or_allreduce_
+    from denovo_kmer_amd.dist import filter_digest, local_reduce_fn, or_allreduce_
 
+    wl = dict(WORKLOADS[args.workload])
+    for key, val in (("k", args.k), ("reads", args.reads), ("batch", args.batch), ("parent_batch", args.parent_batch),
+                     ("windows", args.windows), ("min_count", args.min_count)):
+        if val:
+            wl[key] = val
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -128,31 +217,64 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     on_host = args.backend == "gloo"          # reductions of scalars go through host tensors under gloo
+    sdev = "cpu" if on_host else dev
 
+    wgs = args.workload == "wgs"
+    k, L = wl["k"], wl["read_len"]
+    rec_bytes = 16 if k > 32 else 8
+    if args.set_kind == "exact" and args.workload != "chr20":
+        raise SystemExit("--set-kind exact is a chr20 side measurement")
     if args.log2_bits == 0:
-        args.log2_bits = (36 if args.set_kind == "exact" else 34) + max(0, (world - 1).bit_length())
-    genome_len = args.genome * world
-    gcfg = dk.synth_config(seed=args.seed, genome_len=genome_len, read_len=args.read_len)
-    eng = dk.Engine(k=args.k, filter_log2_bits=args.log2_bits, n_hashes=args.n_hashes, seed=args.seed,
+        args.log2_bits = wl["log2_bits"] if wgs else (36 if args.set_kind == "exact" else wl["log2_bits"]) + max(0, (world - 1).bit_length())
+    # wgs: the job is one trio whose reads are dealt to the ranks; chr20 / ont: every rank brings its own reads of an N x genome
+    reads_total = wl["reads"] if wgs else wl["reads"] * world
+    reads_rank = reads_total // world
+    genome_len = max(reads_total * L // 30, 4 * L)
+    gcfg = dk.synth_config(seed=args.seed, genome_len=genome_len, read_len=L, err_rate=wl["err"])
+    eng = dk.Engine(k=k, filter_log2_bits=args.log2_bits, n_hashes=args.n_hashes, seed=args.seed,
                     device_id=local_rank, mode=args.mode, rank=rank, world_size=world, set_kind=args.set_kind)
+    batch = min(wl["batch"], reads_rank)
+    pbatch = min(wl["parent_batch"], reads_rank)
+    n_batches = (reads_rank + batch - 1) // batch
+    n_pbatches = (reads_rank + pbatch - 1) // pbatch
+
+    def set_hint(b):
+        # a batch covers the genome b*L/genome_len times: capacity planning of the bucket regions (exact for any value)
+        eng.set_option("multiplicity_hint", max(2, int(2 * b * L / genome_len) + 1) if b < reads_rank else 0)
+    set_hint(pbatch)
     filter_bytes = (1 << args.log2_bits) // 8
     filt = torch.zeros(filter_bytes // 8, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     kset = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
     if args.set_kind == "exact":
         kset.clear()                         # an empty exact set is not all-zero memory
-    first = rank * args.reads
+    first = rank * reads_rank
 
-    # ---- parent build (once; reported, not part of `value`) ---------------------------------
-    # (the first insert also grows the engine's workspace pool; the rate is taken from the second parent)
-    insert_ms, insert_windows, insert_stages = 0.0, 0, {}
+    def batch_range(b, size=None):
+        size = size or batch
+        lo = first + b * size
+        return lo, min(size, first + reads_rank - lo)
+
+    # ---- parent build (reported, not part of `value`): every batch of both parents ------------------
+    insert_ms, insert_windows, insert_stages, t_par = 0.0, 0, {}, time.perf_counter()
+    parent_windows = 0
+    progress("parent build: 2 x %d batches of %d reads into a 2^%d-bit set" % (n_pbatches, pbatch, args.log2_bits))
     for s in (0, 1):
-        pb = dk.ReadBatch.synth(eng, gcfg, s, first, args.reads)
-        st = kset.insert_reads(pb)
-        t = eng.timings()
-        insert_ms, insert_windows = t["total_ms"], st["n_windows"]
-        insert_stages = {name: ms for name, ms in t["stages"]}
-        pb.close()
+        for b in range(n_pbatches):
+            lo, n = batch_range(b, pbatch)
+            pb = dk.ReadBatch.synth(eng, gcfg, s, lo, n)
+            st = kset.insert_reads(pb)
+            t = eng.timings()
+            parent_windows += st["n_windows"]
+            if n == pbatch:                  # rate of a full batch, not the first one (which also grows the workspace pool)
+                insert_ms, insert_windows = t["total_ms"], st["n_windows"]
+                insert_stages = {name: ms for name, ms in t["stages"]}
+                insert_stats = st
+            pb.close()
+    torch.cuda.synchronize()
+    parent_seconds = time.perf_counter() - t_par
+    progress("parent build done in %.1f s" % parent_seconds)
+    set_hint(batch)
     allreduce_ms, allreduce_bytes = 0.0, 0
     if world > 1:
         dist.barrier()
@@ -162,99 +284,203 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         allreduce_ms = (time.perf_counter() - t0) * 1e3
-    # every rank must now hold the same filter: compare bit counts across ranks
+    # every rank must now hold the same filter: compare a digest of the words (XOR/sum of mixed words) across ranks
     popc = kset.popcount()
+    digest = filter_digest(filt)
     filter_consistent = True
     if world > 1:
-        pc = torch.tensor([popc, -popc], dtype=torch.int64, device="cpu" if on_host else dev)
-        dist.all_reduce(pc, op=dist.ReduceOp.MAX)
-        filter_consistent = bool(int(pc[0].item()) == -int(pc[1].item()))
+        dg = torch.tensor([digest, -digest, popc, -popc], dtype=torch.int64, device=sdev)
+        dist.all_reduce(dg, op=dist.ReduceOp.MAX)
+        filter_consistent = bool(int(dg[0]) == -int(dg[1]) and int(dg[2]) == -int(dg[3]))
 
-    # ---- child membership pass: warmup + K timed steps -----------------------------------------
-    child = dk.ReadBatch.synth(eng, gcfg, 2, first, args.reads)
-    counter = dk.KmerCounter(eng)
-    stats = None
-    for _ in range(args.warmup):
-        r = counter.child_only(child, kset)
-        stats = r.stats
-        r.close()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    stage_sum, total_dev_ms = {}, 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = counter.child_only(child, kset)
-        stats = r.stats
-        t = eng.timings()                       # HIP events on the engine's stream, this step
+    # ---- child membership pass: warmup + K timed steps -----------------------------------------------
+    stage_sum, total_dev_ms, step_stats = {}, 0.0, None
+    finish_stats, windows_timed = None, 0
+    if wgs:
+        R = wl["windows"]
+        # expected absent occurrences per pass: windows with >= 1 error base, plus filter false positives on the safe side
+        p_err = 1.0 - (1.0 - wl["err"]) ** k
+        cap = int(1.12 * p_err * reads_rank * (L - k + 1) / R)
+        acc = dk.ChildAccumulator(eng, kset, capacity_records=cap, window_index=0, window_count=R)
+        n_res = min(n_batches, args.warmup + args.steps)
+        resident = []
+        for b in range(n_res):
+            lo, n = batch_range(b)
+            resident.append(dk.ReadBatch.synth(eng, gcfg, 2, lo, n))
+        progress("child: %d resident batches, accumulator of %.1f GB" % (n_res, acc.device_bytes() / 1e9))
+        for i in range(args.warmup):
+            acc.add(resident[i % n_res])
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            st = acc.add(resident[(args.warmup + i) % n_res])
+            step_stats = st
+            windows_timed += st["n_windows"]
+            t = eng.timings()
+            total_dev_ms += t["total_ms"]
+            for name, ms in t["stages"]:
+                stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        res = acc.finish(min_count=wl["min_count"])          # counting of what the steps accumulated: part of the job
+        finish_stats = res.stats
+        t = eng.timings()
+        finish_stages = {name: ms for name, ms in t["stages"]}
         total_dev_ms += t["total_ms"]
-        for name, ms in t["stages"]:
-            stage_sum[name] = stage_sum.get(name, 0.0) + ms
-        r.close()
-    torch.cuda.synchronize()
+        res.close()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        windows_done = windows_timed / R                     # a step completes 1/R of its batch's membership work
+        for rb in resident:
+            rb.close()
+    else:
+        R = 1
+        child = dk.ReadBatch.synth(eng, gcfg, 2, first, reads_rank)
+        counter = dk.KmerCounter(eng)
+        for _ in range(args.warmup):
+            r = counter.child_only(child, kset)
+            r.close()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r = counter.child_only(child, kset)
+            step_stats = r.stats
+            windows_timed += r.stats["n_windows"]
+            t = eng.timings()                       # HIP events on the engine's stream, this step
+            total_dev_ms += t["total_ms"]
+            for name, ms in t["stages"]:
+                stage_sum[name] = stage_sum.get(name, 0.0) + ms
+            r.close()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        windows_done = windows_timed
+        finish_stages = {}
     if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        sdev = "cpu" if on_host else dev
         tt = torch.tensor([elapsed], dtype=torch.float64, device=sdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        ww = torch.tensor([stats["n_windows"]], dtype=torch.int64, device=sdev)
+        ww = torch.tensor([windows_done], dtype=torch.float64, device=sdev)
         dist.all_reduce(ww, op=dist.ReduceOp.SUM)
-        windows_all = int(ww.item())
+        windows_all = float(ww.item())
     else:
-        windows_all = stats["n_windows"]
+        windows_all = windows_done
+
+    # ---- wgs: the whole child end to end (all passes, all batches, counting), after the timed steps ----------
+    e2e = None
+    progress("timed steps done")
+    if wgs and not args.no_end_to_end:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_child_only, n_absent_all, child_windows, gen_s = 0, 0, 0, 0.0
+        for w in range(R):
+            acc.reset(w)
+            for b in range(n_batches):
+                lo, n = batch_range(b)
+                tg = time.perf_counter()
+                cb = dk.ReadBatch.synth(eng, gcfg, 2, lo, n)      # generated in place (a real host would upload packed reads here)
+                gen_s += time.perf_counter() - tg
+                st = acc.add(cb)
+                if w == 0:
+                    child_windows += st["n_windows"]
+                cb.close()
+            res = acc.finish(min_count=wl["min_count"])
+            progress("end to end: pass %d of %d counted" % (w + 1, R))
+            n_child_only += len(res)
+            n_absent_all += res.stats["n_absent"]
+            res.close()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        child_seconds = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([child_seconds, gen_s, parent_seconds], dtype=torch.float64, device=sdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            child_seconds, gen_s, parent_seconds = (float(x) for x in tt)
+            cc = torch.tensor([child_windows, n_child_only, n_absent_all, parent_windows], dtype=torch.float64, device=sdev)
+            dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+            child_windows, n_child_only, n_absent_all, parent_windows = (float(x) for x in cc)
+        e2e = {"child_reads": reads_total, "child_windows": child_windows, "child_seconds": child_seconds,
+               "child_seconds_without_read_generation": child_seconds - gen_s,
+               "child_gkmers_s": child_windows / (child_seconds - gen_s) / 1e9,
+               "hash_windows": R, "batches_per_pass": n_batches, "min_count": wl["min_count"],
+               "absent_occurrences": n_absent_all, "child_only_kmers": n_child_only,
+               "parent_reads": 2 * reads_total, "parent_windows": parent_windows, "parent_seconds": parent_seconds,
+               "note": "read generation (synthetic, on the GPU) is inside child_seconds / parent_seconds and subtracted for child_gkmers_s; "
+                       + ("per-rank child-only tables are not merged across ranks in this run" if world > 1 else "one GPU")}
+    if wgs:
+        acc.close()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = windows_all * args.steps / elapsed / 1e9
+        value = windows_all / elapsed / 1e9
         stages = {n: ms / args.steps for n, ms in stage_sum.items()}
-        dom = max(stages, key=stages.get)
-        dom_bytes = stage_algorithmic_bytes(dom, stats, filter_bytes, args.read_len, args.k)
-        achieved = dom_bytes / (stages[dom] * 1e-3) / 1e9 if dom_bytes else None
-        # HBM bytes of the dominant kernel from the committed PMC passes (profiles/traffic.json:
-        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc runs), same configuration only
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                tj = json.load(open(prof))
-                if tj.get("reads") == args.reads and tj.get("log2_bits") == args.log2_bits and world == 1:
-                    traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        sb = {n: stage_algorithmic_bytes(n, step_stats, filter_bytes, rec_bytes, R) for n in stages}
+        if finish_stats:
+            for n, ms in finish_stages.items():            # once per K steps: amortised per step like its time
+                stages[n] = ms / args.steps
+                b = stage_algorithmic_bytes(n, finish_stats, filter_bytes, rec_bytes, R)
+                sb[n] = b / args.steps if b else None
+        traffic, tsrc = committed_traffic(args.workload, wl["reads"], args.log2_bits, world)
+        rl = roofline_of(stages, sb, traffic, tsrc)
+        desc = {
+            "wgs": "configs[2]: k=%d, full 30x WGS synthetic trio, %d x %d bp reads per sample (genome %.2f Gb), parent Bloom 2^%d bits "
+                   "(%d GiB) resident in HBM, child streamed in %d-read batches through %d hash-window passes (dk_accum_add), "
+                   "min_count %d" % (k, reads_total, L, genome_len / 1e9, args.log2_bits, filter_bytes >> 30, batch, R, wl["min_count"]),
+            "chr20": "configs[1]: k=%d, chr20-scale 30x synthetic trio, %d x %d bp reads per sample per GPU, genome %d Mb, parent %s 2^%d "
+                     "bits resident in HBM" % (k, reads_rank, L, genome_len >> 20,
+                                               "Bloom" if args.set_kind == "bloom" else "exact set (open-addressing tables)", args.log2_bits),
+            "ont": "configs[4]: k=%d, ONT-style synthetic trio, %d x %d bp reads per sample per GPU (%.0f %% errors), genome %d Mb, parent "
+                   "Bloom 2^%d bits resident in HBM" % (k, reads_rank, L, 100 * wl["err"], genome_len >> 20, args.log2_bits),
+        }[args.workload]
         out = {
-            "metric": "Gk-mers/sec (child reads vs parent %s), k=%d" % ("Bloom" if args.set_kind == "bloom" else "exact set", args.k),
+            "metric": "Gk-mers/sec (child reads vs parent %s), k=%d" % ("Bloom" if args.set_kind == "bloom" else "exact set", k),
             "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: k=%d, chr20-scale 30x synthetic trio, %d x %d bp reads per sample per GPU, "
-                                   "genome %d Mb, parent %s 2^%d bits resident in HBM"
-                                   % (args.k, args.reads, args.read_len, genome_len >> 20,
-                                      "Bloom" if args.set_kind == "bloom" else "exact set (open-addressing tables)", args.log2_bits),
-                       "k": args.k, "reads_per_gpu": args.reads, "read_len": args.read_len,
-                       "filter_log2_bits": args.log2_bits, "n_hashes": args.n_hashes, "mode": args.mode,
-                       "set_kind": args.set_kind,
+            "config": {"workload": desc, "name": args.workload, "k": k, "reads_per_sample": reads_total, "reads_per_gpu": reads_rank,
+                       "reads_per_step": batch, "read_len": L, "filter_log2_bits": args.log2_bits, "n_hashes": args.n_hashes,
+                       "mode": args.mode, "set_kind": args.set_kind, "hash_windows": R,
+                       "windows_counted_per_step": "n_windows / hash_windows",
                        "parallelism": "reads sharded x%d, %s-all-reduce of parent set" % (world, "OR" if args.set_kind == "bloom" else "union")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "kernel_ms": stages[dom]},
+            "roofline": rl,
             "stages_ms": stages,
             "device_ms_per_step": total_dev_ms / args.steps,
-            "pass_stats": stats,
+            "pass_stats": step_stats,
             "parent_build": {"insert_gkmers_s": insert_windows / (insert_ms * 1e-3) / 1e9 if insert_ms else None,
-                             "insert_ms": insert_ms, "insert_stages_ms": insert_stages,
+                             "insert_ms_per_batch": insert_ms, "insert_stages_ms": insert_stages, "batches": 2 * n_pbatches,
+                             "reads_per_batch": pbatch,
+                             "seconds_all_batches_incl_read_generation": parent_seconds,
                              "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes,
-                             "filter_bits_set": popc, "filter_identical_on_all_ranks": filter_consistent},
+                             "or_allreduce_gbs_per_rank": allreduce_bytes / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None,
+                             "xgmi_peak_gbs_per_rank": 7 * XGMI_LINK_GBS,
+                             "filter_bits_set": popc, "filter_digest": "%016x" % (digest & (2**64 - 1)),
+                             "filter_identical_on_all_ranks": filter_consistent},
         }
+        if insert_ms:
+            ib = {n: stage_algorithmic_bytes(n, insert_stats, filter_bytes, rec_bytes, 1) for n in insert_stages}
+            out["parent_build"]["roofline"] = roofline_of(insert_stages, ib, None, None)
+        if finish_stats:
+            out["finish_stats"] = finish_stats
+        if e2e:
+            out["end_to_end"] = e2e
         if args.set_kind == "exact":
-            out["parent_build"]["exact_set_load"] = popc / (filter_bytes / (16 if args.k > 32 else 8))
+            out["parent_build"]["exact_set_load"] = popc / (filter_bytes / (16 if k > 32 else 8))
         if world == 1 and not args.no_cpu_baseline and args.set_kind == "bloom":
-            out["cpu_baseline"] = cpu_baseline(dk, eng, kset, gcfg, args, min(args.cpu_sample_reads, args.reads))
+            default_sample = {"wgs": 3_000_000, "chr20": 6_000_000, "ont": 12_000}[args.workload]
+            progress("CPU baseline (oracle on a bounded sample, filter copied to the host)")
+            out["cpu_baseline"] = cpu_baseline(dk, eng, kset, gcfg, args, wl, min(args.cpu_sample_reads or default_sample, reads_rank))
         print(json.dumps(out), flush=True)
 
-    child.close()
+    if not wgs:
+        child.close()
     kset.close()
     eng.close()
     if world > 1:

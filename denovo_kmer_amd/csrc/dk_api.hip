@@ -382,7 +382,7 @@ static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, d
         }
     }
     if (st == DK_OK)
-        st = bucketed_count_stage<WIDE>(e, list, a->n_units, Tu, unit_base, a->n_absent, n_aovf, min_count, min_count > 1, res);
+        st = bucketed_count_stage<WIDE>(e, list, a->n_units, Tu, unit_base, a->n_absent, n_aovf, min_count, res);
     pool_free(e, extra);
     pool_free(e, idx);
     return st;

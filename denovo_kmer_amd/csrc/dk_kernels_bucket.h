@@ -558,8 +558,10 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     constexpr int TILE = THREADS * PER_THREAD;
     __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
-    const uint32_t b = blockIdx.y;
-    const uint32_t w = blockIdx.x / tiles_per_piece, t0 = (blockIdx.x % tiles_per_piece) * TILE;
+    // one-dimensional grid (the number of bins can exceed the 65535 of grid.y): bin-major, then piece, then tile
+    const uint32_t per_bin = G * tiles_per_piece;
+    const uint32_t b = blockIdx.x / per_bin, bx = blockIdx.x % per_bin;
+    const uint32_t w = bx / tiles_per_piece, t0 = (bx % tiles_per_piece) * TILE;
     const uint64_t piece = (uint64_t)b * G + w;
     uint32_t n = cnt1[piece];
     if (n > capw) n = capw;
@@ -1041,11 +1043,11 @@ template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE>
 __global__ void __launch_bounds__(CNT_THREADS)
 seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
                  uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
-                 uint32_t *__restrict__ out_cnt, Counters *ctr, uint64_t unit_base, int dry)
+                 uint32_t *__restrict__ out_cnt, Counters *ctr, uint64_t unit_base)
 {
     // unit_base: the units counted are unit_base .. unit_base + n_seg of the 2^T hash-prefix ranges (a window of
-    // an accumulator); dry: count the entries each region would receive (region_fill) without writing any --
-    // dk_accum_finish sizes the table of a min_count > 1 pass with it
+    // an accumulator).  Entries beyond a region's capacity are not written but still tallied in region_fill (and
+    // flagged through n_overflow), so a table sized too small tells how large it has to be.
     using R = typename RecOf<WIDE>::type;
     constexpr int CNT_RPT = (WIDE && CNT_THREADS < 1024) ? 8 : 16;   // records held per thread (the 1024-thread geometry runs one workgroup per CU: 128 VGPRs)
     constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
@@ -1161,7 +1163,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 for (int u = 0; u < CNT_RPT; u++) {
                     const bool uniq = have(c, u) && !flagged(u, hv[u]);
                     const uint64_t bal = __ballot(uniq);
-                    if (uniq && !dry) {
+                    if (uniq) {
                         const uint64_t pos = o + (uint64_t)popc_below(bal);
                         if (pos < region_cap) {
                             out_kmer[region_base + pos] = rec_lo(hv[u], seed);
@@ -1237,7 +1239,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 __syncthreads();
                 uint64_t o = gbase + ex;
                 for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS) {
-                    if (keys[sl] != EMPTY && cnts[sl] >= min_count && !dry) {
+                    if (keys[sl] != EMPTY && cnts[sl] >= min_count) {
                         if (o < region_cap) {
                             if constexpr (WIDE) {
                                 const Rec2 kr{key_h[sl], key_hi[sl]};
@@ -1550,6 +1552,8 @@ inline bool bucketed_pays(const dk_engine *e, uint64_t n_bases, int wbits = 0)
     return filter_bytes >= (32ULL << 20) && n_bases >= (4ULL << 20) && n_bases * 128 >= filter_bytes;
 }
 
+inline unsigned repart_grid(uint64_t blocks_per_bin, uint64_t n_bins) { return (unsigned)(blocks_per_bin * n_bins); }
+
 template <class R>
 struct BucketBufs {
     R *a = nullptr, *b = nullptr;             // level-1 pieces / regions; which one ends up holding the segments' records
@@ -1627,7 +1631,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
     do {                                                                                                  \
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
-        repart_kernel<TH, PT, W, R><<<dim3(p.G * tpp, p.p1), TH, 0, e->stream>>>(                          \
+        repart_kernel<TH, PT, W, R><<<repart_grid(p.G * tpp, p.p1), TH, 0, e->stream>>>(                   \
             B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
             p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr);                                                  \
     } while (0)
@@ -1635,7 +1639,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \
     do {                                                                                                  \
         const uint32_t tpp = (p.capA + TH * PT - 1) / (TH * PT);                                           \
-        repart_kernel<TH, PT, W, R><<<dim3(tpp, 1u << (p.b1 + p.b2)), TH, 0, e->stream>>>(                 \
+        repart_kernel<TH, PT, W, R><<<repart_grid(tpp, 1u << (p.b1 + p.b2)), TH, 0, e->stream>>>(          \
             B.b, B.cursorA, 1u, p.capA, tpp, wbits + p.b1 + p.b2, p.b3, p.cap2, B.a, B.cursor2, ovf, e->d_ctr); \
     } while (0)
     if constexpr (WIDE) {
@@ -1756,35 +1760,37 @@ inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &
 }
 
 // Count the records of `list` unit by unit into res (seg_count): n_units units whose hashes share the top Tc bits
-// (unit_base + local index), n_absent records in all (sizes the table), extra_room more entries per region.
-// dry_first: first run the kernel without writes to learn how many entries pass min_count, and size the table from
-// that (an accumulator of a whole sample with min_count > 1 keeps a small fraction of its records).
+// (unit_base + local index), n_absent records in all, extra_room more entries per region.
+// The table is sized for every record being distinct when min_count == 1.  With min_count > 1 few records
+// survive (a whole-genome child keeps ~1.5 % of its absent occurrences at min_count 2): the table is then sized for
+// an eighth of the upper bound n_absent / min_count, and if a region runs out the kernel has still tallied what
+// each region needs (region_fill), so the count is redone once with exactly that much room.
 template <bool WIDE>
 inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename RecOf<WIDE>::type> &list, uint64_t n_units,
                                       int Tc, uint64_t unit_base, uint64_t n_absent, uint64_t extra_room, uint32_t min_count,
-                                      bool dry_first, dk_result *res)
+                                      dk_result *res)
 {
     if (!n_absent) return DK_OK;
     const uint64_t per_seg = n_absent / n_units;
-    auto launch = [&](uint64_t region_cap, int dry) -> hipError_t {
+    auto launch = [&](uint64_t region_cap) -> hipError_t {
         if (per_seg >= (WIDE ? 3500u : 7000u)) {
             // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
             const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 2);
             seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
         } else if (per_seg >= (WIDE ? 1300u : (uint64_t)(e->opt.cnt_mid > 0 ? e->opt.cnt_mid : 3600))) {
             const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 6);
             seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
         } else if (per_seg >= (WIDE ? 600u : 1200u)) {
             // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each
             const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 12);
             seg_count_kernel<256, 1024, 1024, WIDE><<<cgrid, 256, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
         } else {
             const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 32);
             seg_count_kernel<128, 512, 256, WIDE><<<cgrid, 128, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base, dry);
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
         }
         return hipGetLastError();
     };
@@ -1792,30 +1798,34 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
     // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
     // overflow records may all sit in one segment, hence the extra room for them
     const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, n_units);
-    uint64_t region_cap = n_absent / used_regions + n_absent / (8 * used_regions) + 65536 + extra_room;
+    const uint64_t bound = min_count > 1 ? n_absent / min_count / 8 : n_absent;
+    uint64_t region_cap = bound / used_regions + bound / (8 * used_regions) + 65536 + extra_room;
     dk_status st = DK_OK;
-    if (dry_first) {
-        hipError_t h = launch(~0ULL, 1);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
+        if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
+        if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
+        if (st != DK_OK) return st;
+        const hipError_t h = launch(region_cap);
         if (h != hipSuccess) return fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
-        stage_mark(e, "seg_count_dry");
-        DK_TRY(sync_counters(e, "bucketed count (sizing run)"));
-        region_cap = 1;
-        for (int j = 0; j < RESULT_REGIONS; j++) region_cap = std::max<uint64_t>(region_cap, e->h_ctr->region_fill[j]);
-        // the real run starts from clean tallies (same grid, same walk: every region receives exactly what was counted)
-        e->h_ctr->n_distinct = 0;
+        stage_mark(e, attempt ? "seg_count_redo" : "seg_count");
+        st = sync_counters(e, "bucketed count");
+        uint64_t need = 0;
+        for (int j = 0; j < RESULT_REGIONS; j++) need = std::max<uint64_t>(need, e->h_ctr->region_fill[j]);
+        if (st != DK_ERR_OVERFLOW || attempt || min_count == 1 || need <= region_cap) break;
+        // the optimistic table was too small: same grid, same walk -- every region receives exactly what it was tallied
+        pool_free(e, res->d_lo);
+        pool_free(e, res->d_hi);
+        pool_free(e, res->d_cnt);
+        res->d_lo = res->d_hi = nullptr;
+        res->d_cnt = nullptr;
+        region_cap = need;
+        e->h_ctr->n_distinct = e->h_ctr->n_overflow = 0;
         hipError_t h2 = hipMemsetAsync(e->d_ctr->region_fill, 0, sizeof e->h_ctr->region_fill, e->stream);
         if (h2 == hipSuccess) h2 = hipMemsetAsync(&e->d_ctr->n_distinct, 0, 8, e->stream);
+        if (h2 == hipSuccess) h2 = hipMemsetAsync(&e->d_ctr->n_overflow, 0, 8, e->stream);
         if (h2 != hipSuccess) return fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h2));
     }
-    st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_lo);
-    if (st == DK_OK && WIDE) st = pool_alloc(e, region_cap * RESULT_REGIONS * 8, (void **)&res->d_hi);
-    if (st == DK_OK) st = pool_alloc(e, region_cap * RESULT_REGIONS * 4, (void **)&res->d_cnt);
-    if (st == DK_OK) {
-        hipError_t h = launch(region_cap, 0);
-        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_count launch failed: %s", hipGetErrorString(h));
-        else stage_mark(e, "seg_count");
-    }
-    if (st == DK_OK) st = sync_counters(e, "bucketed count");
     if (st == DK_OK) {
         res->n_regions = RESULT_REGIONS;
         res->region_cap = region_cap;
@@ -1913,9 +1923,11 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     // in registers (16 K), and its multi-chunk path is slow (150 ms at 16 K per segment).  The absent lists are
     // then split once more by the next hash bits -- the level-3 use of repart, over the absent lists instead of
     // coarse regions -- into units of ~5 K records; the space of the probed records is free for the result.
-    if (st == DK_OK && s && unit_pieces == 1 && !list.extra && p.T <= 15 && n_absent / p.n_seg > 14000) {
+    // (a seg_count workgroup holds 16 K records of 8 bytes, 8 K of 16)
+    const uint64_t split_above = WIDE ? 7000 : 14000, split_to = WIDE ? 3000 : 6000;
+    if (st == DK_OK && s && unit_pieces == 1 && !list.extra && n_absent / p.n_seg > split_above) {
         int bs = 1;
-        while (bs < MAX_BIN_BITS && (n_absent >> (p.T + bs)) > 6000) bs++;
+        while (bs < MAX_BIN_BITS && (n_absent >> (p.T + bs)) > split_to) bs++;
         const uint64_t n_fine = p.n_seg << bs;
         const uint32_t cap_f = piece_capacity((double)n_absent / (double)n_fine, 16.0);   // an overflowing unit only costs the fallback
         if (p.T + bs <= MAX_SEG_BITS) {
@@ -1932,7 +1944,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
                 const OvfList<R> none{nullptr, &e->d_ctr->dbg[0], 0};
                 constexpr int TH = WIDE ? 512 : 1024;
                 const uint32_t tpp = (p.cap2 + TH * 8 - 1) / (TH * 8);
-                repart_kernel<TH, 8, 8, R><<<dim3(tpp, (unsigned)p.n_seg), TH, 0, e->stream>>>(
+                repart_kernel<TH, 8, 8, R><<<repart_grid(tpp, p.n_seg), TH, 0, e->stream>>>(
                     B.scratch, B.miss_cnt, 1u, p.cap2, tpp, p.T, bs, cap_f, fine_out, B.fine_cursor, none, e->d_ctr);
                 h = hipGetLastError();
                 if (h == hipSuccess) h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
@@ -1954,7 +1966,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         }
     }
     if (st == DK_OK)
-        st = bucketed_count_stage<WIDE>(e, list, n_units, Tc, 0, n_absent, e->h_ctr->n_ovf_miss, e->cfg.min_count, false, res);
+        st = bucketed_count_stage<WIDE>(e, list, n_units, Tc, 0, n_absent, e->h_ctr->n_ovf_miss, e->cfg.min_count, res);
     free_bufs(e, B);
     return st;
 }

@@ -52,6 +52,8 @@ def local_reduce_fn(engine, group=None):
 def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
     """In-place all-reduce of the parent set `filt` (1-D int64 tensor, one per rank, equal sizes):
     bitwise OR for a Bloom filter (or_fn = hip_or_fn), key union for an exact set (hip_union_fn).
+    On return the result is complete in device memory for every stream (the call ends with a device
+    synchronize: the collectives run on torch's stream, the engine probes on its own).
 
     or_fn(dst, src, n_slices): dst <- dst combined with the n_slices contiguous slices in src.
     stage_through_cpu: move the payload through host memory around each collective (for rehearsing
@@ -81,7 +83,25 @@ def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
         filt.copy_(out_h)
     else:
         dist.all_gather_into_tensor(filt, reduced, group=group)
+        # the gather is ordered only against torch's current stream; the engine's stream (hipStreamNonBlocking)
+        # reads `filt` next, so the in-place contract needs the device to be idle here
+        if filt.is_cuda:
+            torch.cuda.synchronize()
+        del recv, reduced
     return 2 * (world - 1) * sl * filt.element_size()
+
+
+def filter_digest(filt, chunk_words=1 << 24):
+    """position-sensitive 64-bit digest of a set's words, sum of w[i] * (2 i + 1) mod 2^64 (as a signed int),
+    computed in chunks on the device: equal filters <=> equal digests up to a 2^-64 accident, unlike a bit count"""
+    assert filt.dim() == 1 and filt.dtype == torch.int64
+    acc = torch.zeros((), dtype=torch.int64, device=filt.device)
+    n = filt.numel()
+    for lo in range(0, n, chunk_words):
+        c = filt[lo:lo + chunk_words]
+        idx = torch.arange(lo, lo + c.numel(), dtype=torch.int64, device=filt.device)
+        acc += (c * (2 * idx + 1)).sum()
+    return int(acc.item())
 
 
 def merge_counts(hi, lo, cnt, min_count=1, group=None):

@@ -1,3 +1,4 @@
+#define _POSIX_C_SOURCE 200809L
 /*
  * dk_oracle.c -- CPU oracle (plain C) for the denovo_kmer hot path.  TEST INFRASTRUCTURE ONLY.
  *
@@ -8,6 +9,7 @@
 #include "dk_oracle.h"
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <math.h>
 
 typedef unsigned __int128 u128;
@@ -203,6 +205,19 @@ static void probe_range(const uint64_t *filter, int log2_bits, int n_hashes, uin
     free(km); free(va);
 }
 
+/* wall seconds of the phases of the last orc_bloom_probe_reads_mt call: [0] extraction + hashing + filter probe
+ * (parallel over reads), [1] per-thread sort of the absent lists (parallel), [2] serial multi-way merge + counting.
+ * bench.py reports them apart: only [0] is the membership path proper. */
+static double g_phase_s[3];
+void orc_last_phase_seconds(double *out) { out[0] = g_phase_s[0]; out[1] = g_phase_s[1]; out[2] = g_phase_s[2]; }
+
+static double wall_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int64_t orc_bloom_probe_reads_mt(const uint64_t *filter, int log2_bits, int n_hashes, uint64_t seed,
                                  int k, int canonical, uint32_t min_count,
                                  const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,
@@ -212,14 +227,17 @@ int64_t orc_bloom_probe_reads_mt(const uint64_t *filter, int log2_bits, int n_ha
     if (n_threads < 1) n_threads = 1;
     uint64_t ml = max_read_len(offsets, n_reads);
     probe_part *parts = (probe_part *)calloc((size_t)n_threads, sizeof(probe_part));
+    const double t_start = wall_s();
 #pragma omp parallel for num_threads(n_threads) schedule(static, 1)
     for (int t = 0; t < n_threads; t++) {
         uint64_t r0 = n_reads * (uint64_t)t / (uint64_t)n_threads, r1 = n_reads * (uint64_t)(t + 1) / (uint64_t)n_threads;
         probe_range(filter, log2_bits, n_hashes, seed, k, canonical, seq, offsets, r0, r1, ml, &parts[t]);
     }
+    const double t_probe = wall_s();
     /* every thread sorts its own absent list; one linear multi-way merge then counts runs */
 #pragma omp parallel for num_threads(n_threads) schedule(static, 1)
     for (int t = 0; t < n_threads; t++) qsort(parts[t].list, parts[t].n, sizeof(orc_kmer), cmp_kmer);
+    const double t_sort = wall_s();
     orc_stats st = {0};
     for (int t = 0; t < n_threads; t++) {
         st.n_reads += parts[t].st.n_reads;
@@ -257,6 +275,9 @@ int64_t orc_bloom_probe_reads_mt(const uint64_t *filter, int log2_bits, int n_ha
         cur_n = 1;
         have_cur = 1;
     }
+    g_phase_s[0] = t_probe - t_start;
+    g_phase_s[1] = t_sort - t_probe;
+    g_phase_s[2] = wall_s() - t_sort;
     for (int t = 0; t < n_threads; t++) free(parts[t].list);
     free(parts);
     free(head);

@@ -66,6 +66,8 @@ int64_t orc_bloom_probe_reads(const uint64_t *filter, int log2_bits, int n_hashe
                               orc_stats *stats);
 
 /* Same result with the reads split over n_threads OpenMP threads (bench.py's cpu_baseline). */
+/* wall seconds of the last orc_bloom_probe_reads_mt call: [0] probe (parallel), [1] sort (parallel), [2] merge (serial) */
+void orc_last_phase_seconds(double *out);
 int64_t orc_bloom_probe_reads_mt(const uint64_t *filter, int log2_bits, int n_hashes, uint64_t seed,
                                  int k, int canonical, uint32_t min_count,
                                  const uint8_t *seq, const uint64_t *offsets, uint64_t n_reads,

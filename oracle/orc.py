@@ -65,6 +65,8 @@ def lib():
         L.orc_bloom_probe_reads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                             C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
                                             C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(OrcStats)]
+        L.orc_last_phase_seconds.restype = None
+        L.orc_last_phase_seconds.argtypes = [C.POINTER(C.c_double)]
         L.orc_bloom_probe_reads_mt.restype = C.c_int64
         L.orc_bloom_probe_reads_mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64,
@@ -158,6 +160,13 @@ def bloom_probe(filt, log2_bits, n_hashes, seed, k, canonical, seq, offsets, min
                                        _ptr(km), _ptr(cn), cap, C.byref(st), n_threads)
     assert n >= 0
     return km[:n].copy(), cn[:n].copy(), st.as_dict()
+
+
+def last_phase_seconds():
+    """(probe, sort, merge) wall seconds of the last bloom_probe call"""
+    out = (C.c_double * 3)()
+    lib().orc_last_phase_seconds(out)
+    return float(out[0]), float(out[1]), float(out[2])
 
 
 def exact_child_only(k, canonical, pseq, poff, cseq, coff, min_count=1):

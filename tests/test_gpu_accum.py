@@ -228,3 +228,26 @@ def test_many_batches_against_a_2_to_the_36_bit_filter():
             sums[mode] = ks.popcount()
             ks.close()
     assert sums["bucketed"] == sums["direct"]
+
+
+def test_min_count_table_too_small_is_recounted_exactly():
+    """with min_count > 1 the result table is sized for an eighth of the upper bound; a sample where nearly every
+    k-mer passes the threshold overruns it and is counted a second time with the room the first run tallied"""
+    d = dk()
+    rng = np.random.default_rng(8)
+    reads = random_reads(rng, 30000, 150, 151)
+    seq, off = orc.concat_reads(reads + reads)
+    km, cn, ost = orc.count_reads(31, True, seq, off)
+    assert int(cn.min()) >= 2
+    with d.Engine(k=31, filter_log2_bits=26, seed=1, mode="bucketed") as eng:
+        acc = d.ChildAccumulator(eng, None, capacity_records=8_000_000)
+        for _ in range(2):
+            acc.add(d.ReadBatch.from_sequences(eng, reads))
+        res = acc.finish(min_count=2)
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert names[-2:] == ["seg_count", "seg_count_redo"], names
+        hi, lo, cnt = res.to_host(sort=True)
+        assert np.array_equal(lo, km["lo"]) and np.array_equal(hi, km["hi"]) and np.array_equal(cnt, cn)
+        assert res.stats["n_distinct"] == ost["n_distinct"] == len(lo)
+        res.close()
+        acc.close()
