@@ -192,7 +192,7 @@ def main():
     import torch.distributed as dist
 
     import denovo_kmer_amd as dk
-    from denovo_kmer_amd.dist import filter_digest, local_reduce_fn, or_allreduce_
+    from denovo_kmer_amd.dist import comm_init_from_torch, filter_digest, local_reduce_fn, or_allreduce_
 
     wl = dict(WORKLOADS[args.workload])
     for key, val in (("k", args.k), ("reads", args.reads), ("batch", args.batch), ("parent_batch", args.parent_batch),
@@ -275,12 +275,30 @@ def main():
     parent_seconds = time.perf_counter() - t_par
     progress("parent build done in %.1f s" % parent_seconds)
     set_hint(batch)
-    allreduce_ms, allreduce_bytes = 0.0, 0
+    allreduce_ms, allreduce_bytes, allreduce_path = 0.0, 0, None
     if world > 1:
+        # native path: the library's own RCCL communicator (dk_comm_init + dk_set_allreduce_or), as a host without torch
+        # would run it; the gloo rehearsal (several ranks on one GPU) and any failure to set it up use the
+        # torch.distributed composition of the same three steps
+        native = False
+        if not on_host and not args.single_device:
+            try:
+                comm_init_from_torch(eng)
+                native = True
+            except Exception as exc:                       # noqa: BLE001 -- reported, the torch path takes over
+                progress("native RCCL communicator unavailable (%s): torch.distributed path" % exc)
+        flags = torch.tensor([1 if native else 0], dtype=torch.int64, device=sdev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        native = bool(int(flags.item()))
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        allreduce_bytes = or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=on_host)
+        if native:
+            allreduce_bytes = kset.allreduce_or()
+            allreduce_path = "dk_set_allreduce_or (RCCL send/recv + HIP OR kernel + ncclAllGather on the engine stream)"
+        else:
+            allreduce_bytes = or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=on_host)
+            allreduce_path = "torch.distributed all_to_all_single + dk_or_reduce_slices + all_gather_into_tensor" + (" staged through the host (gloo rehearsal)" if on_host else "")
         torch.cuda.synchronize()
         dist.barrier()
         allreduce_ms = (time.perf_counter() - t0) * 1e3
@@ -459,6 +477,7 @@ def main():
                              "reads_per_batch": pbatch,
                              "seconds_all_batches_incl_read_generation": parent_seconds,
                              "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes,
+                             "or_allreduce_path": allreduce_path,
                              "or_allreduce_gbs_per_rank": allreduce_bytes / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None,
                              "xgmi_peak_gbs_per_rank": 7 * XGMI_LINK_GBS,
                              "filter_bits_set": popc, "filter_digest": "%016x" % (digest & (2**64 - 1)),

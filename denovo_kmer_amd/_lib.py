@@ -103,6 +103,10 @@ SYMBOLS = {
     "dk_or_reduce_slices": (C.c_int32, [_P, _P, _P, _U64, _U64]),
     "dk_union_slices": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64]),
     "dk_set_destroy": (None, [_P]),
+    "dk_comm_unique_id": (C.c_int32, [_P]),
+    "dk_comm_init": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32]),
+    "dk_comm_finalize": (C.c_int32, [_P]),
+    "dk_set_allreduce_or": (C.c_int32, [_P, _PU64]),
     "dk_probe": (C.c_int32, [_P, _P, _P, _PP, C.POINTER(DkStats)]),
     "dk_result_size": (C.c_int32, [_P, _PU64]),
     "dk_result_copy": (C.c_int32, [_P, _P, _P, _P]),

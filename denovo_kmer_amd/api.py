@@ -90,6 +90,21 @@ class Engine:
         validated test hooks that force a kernel geometry ("scan_variant", "force_l3", ...)"""
         self.check(self._lib.dk_engine_set_option(self.handle, name.encode(), int(value)))
 
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL id (dk_comm_unique_id): one rank creates it, the host hands it to the others"""
+        buf = (C.c_uint8 * 128)()
+        check(_lib.load().dk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world_size):
+        """collective: join this engine to the RCCL communicator identified by unique_id (dk_comm_init)"""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        self.check(self._lib.dk_comm_init(self.handle, buf, rank, world_size))
+
+    def comm_finalize(self):
+        self.check(self._lib.dk_comm_finalize(self.handle))
+
     def or_reduce_slices(self, dst_ptr, src_ptr, n_slices, slice_bytes):
         """dst |= OR of n_slices slices at src (device pointers): local step of the OR-all-reduce."""
         self.check(self._lib.dk_or_reduce_slices(self.handle, C.c_void_p(dst_ptr), C.c_void_p(src_ptr),
@@ -356,6 +371,13 @@ class KmerSet:
 
     def clear(self):
         self.engine.check(self.engine._lib.dk_set_clear(self._h))
+
+    def allreduce_or(self):
+        """collective over the engine's communicator (Engine.comm_init): combine the ranks' sets in place -- OR for a
+        Bloom filter, union for an exact set (dk_set_allreduce_or).  -> bytes sent by this rank"""
+        n = C.c_uint64()
+        self.engine.check(self.engine._lib.dk_set_allreduce_or(self._h, C.byref(n)))
+        return int(n.value)
 
     def popcount(self):
         n = C.c_uint64()

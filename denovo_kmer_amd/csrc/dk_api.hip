@@ -10,6 +10,7 @@
 
 #include "dk_internal.h"
 #include "dk_kernels_bucket.h"
+#include "dk_comm.h"
 
 static thread_local std::string g_create_err;
 
@@ -45,6 +46,7 @@ dk_status pool_alloc(dk_engine *e, size_t bytes, void **out)
     void *p = nullptr;
     hipError_t r = hipMalloc(&p, bytes);
     if (r != hipSuccess) {
+        (void)hipGetLastError();     // the failure is handled here: do not leave it for the next hipGetLastError()
         // release every cached free block and retry once
         for (auto &b : e->pool)
             if (!b.in_use && b.ptr) { (void)hipFree(b.ptr); b.ptr = nullptr; b.bytes = 0; }
@@ -52,8 +54,10 @@ dk_status pool_alloc(dk_engine *e, size_t bytes, void **out)
                                      [](const dk_pool_block &b) { return b.ptr == nullptr; }),
                       e->pool.end());
         r = hipMalloc(&p, bytes);
-        if (r != hipSuccess)
+        if (r != hipSuccess) {
+            (void)hipGetLastError();
             return fail(e, DK_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+        }
     }
     e->pool.push_back({p, bytes, true});
     *out = p;
@@ -477,6 +481,7 @@ void dk_engine_destroy(dk_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    (void)dk_comm_finalize(e);
     for (auto &b : e->pool)
         if (b.ptr) (void)hipFree(b.ptr);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
@@ -1173,6 +1178,72 @@ dk_status dk_union_slices(dk_engine *e, void *d_dst, const void *d_src, uint64_t
     DK_HIP(e, hipGetLastError());
     DK_TRY(read_counters(e));
     if (e->h_ctr->n_set_full) return set_full(e);
+    return DK_OK;
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------------------------
+dk_status dk_comm_unique_id(uint8_t *id)
+{
+    if (!id) return fail(nullptr, DK_ERR_INVALID_ARG, "id is NULL");
+    RcclApi *api = rccl();
+    if (!api->lib) return fail(nullptr, DK_ERR_UNSUPPORTED, "%s", api->err.c_str());
+    ncclUniqueId_t u;
+    const int r = api->GetUniqueId(&u);
+    if (r != RCCL_SUCCESS) return fail(nullptr, DK_ERR_HIP, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    static_assert(sizeof u == DK_COMM_ID_BYTES, "ncclUniqueId is 128 bytes (rccl.h:40)");
+    memcpy(id, &u, sizeof u);
+    return DK_OK;
+}
+
+dk_status dk_comm_init(dk_engine *e, const uint8_t *id, uint32_t rank, uint32_t world_size)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, world_size >= 1 && rank < world_size);
+    CHECK_ARG(e, id != nullptr || world_size == 1);
+    CHECK_ARG(e, e->comm == nullptr);
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_comm *c = new (std::nothrow) dk_comm();
+    if (!c) return fail(e, DK_ERR_OOM, "host allocation failed");
+    c->comm = nullptr;
+    c->rank = rank;
+    c->world = world_size;
+    c->staging = nullptr;
+    c->staging_bytes = 0;
+    if (world_size > 1) {
+        RcclApi *api = rccl();
+        if (!api->lib) { delete c; return fail(e, DK_ERR_UNSUPPORTED, "%s", api->err.c_str()); }
+        ncclUniqueId_t u;
+        memcpy(&u, id, sizeof u);
+        const int r = api->CommInitRank(&c->comm, (int)world_size, u, (int)rank);
+        if (r != RCCL_SUCCESS) { delete c; return fail(e, DK_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(r)); }
+        c->staging_bytes = 1ULL << 30;
+        const dk_status st = pool_alloc(e, c->staging_bytes, &c->staging);
+        if (st != DK_OK) { (void)api->CommDestroy(c->comm); delete c; return st; }
+    }
+    e->comm = c;
+    e->cfg.rank = rank;
+    e->cfg.world_size = world_size;
+    return DK_OK;
+}
+
+dk_status dk_comm_finalize(dk_engine *e)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    if (!e->comm) return DK_OK;
+    if (e->comm->comm) (void)rccl()->CommDestroy(e->comm->comm);
+    pool_free(e, e->comm->staging);
+    delete e->comm;
+    e->comm = nullptr;
+    return DK_OK;
+}
+
+dk_status dk_set_allreduce_or(dk_set *s, uint64_t *bytes_sent)
+{
+    if (!s) return DK_ERR_INVALID_ARG;
+    dk_engine *e = s->e;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_TRY(dk::set_allreduce(e, s, bytes_sent));
+    if (e->comm && e->comm->world > 1 && e->h_ctr->n_set_full) return set_full(e);
     return DK_OK;
 }
 

@@ -1,0 +1,141 @@
+// dk_comm.h -- RCCL behind the C ABI: dk_comm_* and dk_set_allreduce (include/denovo_kmer.h).
+//
+// The one exchange step of the hot path: every rank holds a partial parent set of the FULL size,
+// built from its parent-read shard; the partials are combined in place.  RCCL has no bitwise-OR reduction
+// (ncclRedOp_t = sum/prod/max/min/avg, rccl.h:448-453), so the all-reduce is composed on the engine's stream:
+//
+//   chunk by chunk:  all-to-all (ncclSend / ncclRecv inside one group): rank r receives piece j of slice r from
+//                    every other rank into a staging buffer;  or_slices_kernel (Bloom) / union_slices_kernel (exact)
+//                    combines the P - 1 pieces into rank r's own slice
+//   once:            ncclAllGather in place: every rank receives every combined slice
+//
+// On a fully connected xGMI node every phase drives all 7 links of a GPU at once (a ring all-reduce is bound by
+// one link).  The staging buffer is bounded (1 GiB by default), so a 64-GiB filter needs no second 64 GiB.
+// librccl is loaded on first use (dlopen "librccl.so.1": in a process that already holds PyTorch's copy the loader
+// hands back that one), so the library itself carries no link-time dependency on it.
+#pragma once
+#include <dlfcn.h>
+
+#include "dk_internal.h"
+#include "dk_kernels_bucket.h"
+
+namespace dk {
+
+// the subset of rccl.h this file calls (types as declared there: rccl.h:43, 459-470, 187-720)
+typedef struct ncclComm *ncclComm_t;
+struct ncclUniqueId_t { char internal[128]; };
+enum { RCCL_SUCCESS = 0, RCCL_UINT8 = 1 };
+
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(ncclUniqueId_t *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId_t, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+
+inline RcclApi *rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return &api;
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) { api.err = std::string("cannot load librccl: ") + dlerror(); return &api; }
+    struct { const char *name; void **slot; } syms[] = {
+        {"ncclGetUniqueId", (void **)&api.GetUniqueId}, {"ncclCommInitRank", (void **)&api.CommInitRank},
+        {"ncclCommDestroy", (void **)&api.CommDestroy}, {"ncclGroupStart", (void **)&api.GroupStart},
+        {"ncclGroupEnd", (void **)&api.GroupEnd},       {"ncclSend", (void **)&api.Send},
+        {"ncclRecv", (void **)&api.Recv},               {"ncclAllGather", (void **)&api.AllGather},
+        {"ncclGetErrorString", (void **)&api.GetErrorString},
+    };
+    for (auto &s : syms) {
+        *s.slot = dlsym(api.lib, s.name);
+        if (!*s.slot) { api.err = std::string("librccl lacks ") + s.name; api.lib = nullptr; return &api; }
+    }
+    return &api;
+}
+
+}  // namespace dk
+
+struct dk_comm {
+    dk::ncclComm_t comm;
+    uint32_t rank, world;
+    void *staging;              // pool block for the received pieces
+    uint64_t staging_bytes;
+};
+
+namespace dk {
+
+#define DK_RCCL(e, call)                                                                                     \
+    do {                                                                                                     \
+        const int _r = (call);                                                                               \
+        if (_r != RCCL_SUCCESS)                                                                              \
+            return fail((e), DK_ERR_HIP, "%s failed: %s (%s:%d)", #call, rccl()->GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+// the slices of the set are combined in pieces of `piece` bytes (a multiple of 64 KiB) so that the P - 1 received
+// pieces fit the staging buffer
+inline dk_status set_allreduce(dk_engine *e, dk_set *s, uint64_t *bytes_sent)
+{
+    dk_comm *c = e->comm;
+    if (bytes_sent) *bytes_sent = 0;
+    if (!c || c->world == 1) return DK_OK;
+    RcclApi *api = rccl();
+    const uint64_t P = c->world, r = c->rank;
+    if (s->n_bytes % (P * SEG_BYTES) != 0)
+        return fail(e, DK_ERR_UNSUPPORTED, "the set (%llu bytes) does not split into whole 64-KiB segments over %llu ranks",
+                    (unsigned long long)s->n_bytes, (unsigned long long)P);
+    const uint64_t sl = s->n_bytes / P;
+    uint64_t piece = c->staging_bytes / (P - 1) / SEG_BYTES * SEG_BYTES;
+    if (piece > sl) piece = sl;
+    if (piece == 0) return fail(e, DK_ERR_INVALID_ARG, "staging buffer below 64 KiB per peer");
+    char *base = (char *)s->d_words;
+    const int T = (int)e->cfg.filter_log2_bits - 19;
+    hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+    if (h != hipSuccess) return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h));
+    for (uint64_t off = 0; off < sl; off += piece) {
+        const uint64_t nb = std::min(piece, sl - off);
+        DK_RCCL(e, api->GroupStart());
+        for (uint64_t q = 0; q < P; q++) {
+            if (q == r) continue;
+            // piece of slice q goes to rank q; the same piece of my slice comes from rank q
+            DK_RCCL(e, api->Send(base + q * sl + off, nb, RCCL_UINT8, (int)q, c->comm, e->stream));
+            DK_RCCL(e, api->Recv((char *)c->staging + (q < r ? q : q - 1) * nb, nb, RCCL_UINT8, (int)q, c->comm, e->stream));
+        }
+        DK_RCCL(e, api->GroupEnd());
+        char *dst = base + r * sl + off;
+        if (s->exact) {
+            const uint64_t first_seg = (r * sl + off) / SEG_BYTES, n_seg = nb / SEG_BYTES;
+            if (e->cfg.k > 32)
+                union_slices_kernel<true><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
+                    (unsigned long long *)dst, (const unsigned long long *)c->staging, P - 1, nb / 8, first_seg, T, e->d_ctr);
+            else
+                union_slices_kernel<false><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
+                    (unsigned long long *)dst, (const unsigned long long *)c->staging, P - 1, nb / 8, first_seg, T, e->d_ctr);
+        } else {
+            or_slices_kernel<<<grid_for(e, nb / 16, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                (uint4 *)dst, (const uint4 *)c->staging, P - 1, nb / 16);
+        }
+        h = hipGetLastError();
+        if (h != hipSuccess) return fail(e, DK_ERR_HIP, "slice reduction failed: %s", hipGetErrorString(h));
+    }
+    DK_RCCL(e, api->AllGather(base + r * sl, base, sl, RCCL_UINT8, c->comm, e->stream));
+    h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    if (h != hipSuccess) return fail(e, DK_ERR_HIP, "all-reduce of the set failed: %s", hipGetErrorString(h));
+    if (bytes_sent) *bytes_sent = 2 * (P - 1) * sl;
+    return DK_OK;
+}
+
+}  // namespace dk

@@ -29,9 +29,12 @@ struct dk_options {
     int merge_idx64 = 0;          // dk_result_merge: 64-bit candidate indices whatever the size
 };
 
+struct dk_comm;
+
 struct dk_engine {
     dk_config cfg;
     dk_options opt;
+    dk_comm *comm = nullptr;      // RCCL communicator (dk_comm_init), or none
     int device;
     int n_cu;
     hipStream_t stream;

@@ -91,6 +91,18 @@ def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
     return 2 * (world - 1) * sl * filt.element_size()
 
 
+def comm_init_from_torch(engine, group=None):
+    """Join `engine` to an RCCL communicator of its own behind the C ABI (dk_comm_init), using torch.distributed
+    only to hand rank 0's 128-byte id to the other ranks.  After this KmerSet.allreduce_or() runs the composed
+    all-reduce natively on the engine's stream -- the path a Rust host takes (it has no torch)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    box = [engine.comm_unique_id() if rank == 0 and world > 1 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(box[0], rank, world)
+
+
 def filter_digest(filt, chunk_words=1 << 24):
     """position-sensitive 64-bit digest of a set's words, sum of w[i] * (2 i + 1) mod 2^64 (as a signed int),
     computed in chunks on the device: equal filters <=> equal digests up to a 2^-64 accident, unlike a bit count"""

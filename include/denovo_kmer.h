@@ -68,7 +68,6 @@ typedef struct dk_reads dk_reads;     /* device-resident packed read batch */
 typedef struct dk_set dk_set;         /* KmerSet: parent blocked-Bloom filter resident in HBM */
 typedef struct dk_result dk_result;   /* k-mer -> count table (child-only set, or KmerCounter output) */
 typedef struct dk_accum dk_accum;     /* child-only k-mer occurrences of many batches, counted once at the end */
-typedef struct dk_comm dk_comm;       /* RCCL communicator of an engine (one rank per GPU) */
 
 typedef struct dk_config {
     uint64_t struct_size;        /* = sizeof(dk_config); versions the struct */
@@ -191,6 +190,21 @@ dk_status dk_or_reduce_slices(dk_engine *e, void *d_dst, const void *d_src,
 dk_status dk_union_slices(dk_engine *e, void *d_dst, const void *d_src, uint64_t n_slices,
                           uint64_t slice_bytes, uint64_t first_segment);
 void      dk_set_destroy(dk_set *s);
+
+/* ---- multi-GPU: one process (or thread) per GPU, one engine each; the parent set is the only thing exchanged ----
+ * Reads shard across the ranks; every rank inserts its parent shard into a set of the FULL size; dk_set_allreduce_or
+ * then combines the ranks' sets in place -- bitwise OR for a Bloom filter, key union for DK_SET_EXACT -- after which
+ * every rank holds the whole parent set and probes its child shard locally.  RCCL has no OR reduction, so the
+ * library composes it on the engine's stream: all-to-all of slices (ncclSend/ncclRecv) -> local OR / union kernel ->
+ * ncclAllGather, in pieces that bound the staging memory (1 GiB).  librccl.so.1 is loaded on first use.
+ *   dk_comm_unique_id  one rank creates the id; the host hands the 128 bytes to the other ranks (MPI, TCP, a file)
+ *   dk_comm_init       collective over all ranks: joins the engine to the communicator (one per engine)
+ *   dk_set_allreduce_or  collective; a no-op with world_size 1 or without a communicator; bytes_sent may be NULL */
+#define DK_COMM_ID_BYTES 128
+dk_status dk_comm_unique_id(uint8_t *id /* DK_COMM_ID_BYTES */);
+dk_status dk_comm_init(dk_engine *e, const uint8_t *id /* DK_COMM_ID_BYTES */, uint32_t rank, uint32_t world_size);
+dk_status dk_comm_finalize(dk_engine *e);
+dk_status dk_set_allreduce_or(dk_set *s, uint64_t *bytes_sent);
 
 /* ---- membership pass + KmerCounter (replaces: child loop of counter.rs) ---------------------- */
 /* probe every window of r against s; absent k-mers are counted.  s == NULL counts every k-mer

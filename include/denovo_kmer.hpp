@@ -215,5 +215,54 @@ private:
     Engine &e_;
 };
 
+// A child that arrives in many batches (dk_accum_*): add() every batch, finish() once -- counts and min_count are
+// exact over the whole sample.  windows > 1: stream the sample once per window, reset(w) before pass w.
+class ChildAccumulator {
+public:
+    ChildAccumulator(Engine &e, const KmerSet *parents, uint64_t capacity_records, uint32_t window_count = 1) : e_(e)
+    {
+        check(dk_accum_create(e.get(), parents ? parents->get() : nullptr, 0, window_count, capacity_records, &a_), e.get());
+    }
+    ~ChildAccumulator() { dk_accum_destroy(a_); }
+    ChildAccumulator(const ChildAccumulator &) = delete;
+    ChildAccumulator &operator=(const ChildAccumulator &) = delete;
+    dk_stats add(const ReadBatch &b)
+    {
+        dk_stats st;
+        check(dk_accum_add(a_, b.get(), &st), e_.get());
+        return st;
+    }
+    void reset(uint32_t window_index) { check(dk_accum_reset(a_, window_index), e_.get()); }
+    // appends the window's table to `out` (k-mers of different windows are disjoint)
+    void finish(uint32_t min_count, KmerCounts &out)
+    {
+        dk_result *res = nullptr;
+        dk_stats st;
+        check(dk_accum_finish(a_, min_count, &res, &st), e_.get());
+        uint64_t n = 0;
+        dk_status rc = dk_result_size(res, &n);
+        const size_t at = out.lo.size();
+        if (rc == DK_OK && n) {
+            out.lo.resize(at + n);
+            out.hi.resize(at + n);
+            out.count.resize(at + n);
+            rc = dk_result_copy(res, out.lo.data() + at, out.hi.data() + at, out.count.data() + at);
+        }
+        dk_result_destroy(res);
+        check(rc, e_.get());
+        out.stats.n_reads = st.n_reads;
+        out.stats.n_bases = st.n_bases;
+        out.stats.n_windows = st.n_windows;
+        out.stats.n_valid = st.n_valid;
+        out.stats.n_absent += st.n_absent;
+        out.stats.n_distinct += st.n_distinct;
+        out.stats.n_emitted += st.n_emitted;
+    }
+
+private:
+    Engine &e_;
+    dk_accum *a_ = nullptr;
+};
+
 }  // namespace dk_host
 #endif

@@ -26,6 +26,24 @@ def test_header_and_binding_agree():
     assert declared_symbols() == sorted(_lib.SYMBOLS)
 
 
+def test_integration_md_rust_block_matches_the_header():
+    """INTEGRATION.md's `extern "C"` block is generated from the header (tools/gen_rust_extern.py); a Rust toolchain
+    is absent, so this comparison -- every function, every argument name and type -- is the guard against drift"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_rust_extern", os.path.join(ROOT, "tools", "gen_rust_extern.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a = md.index('extern "C" {')
+    block = md[a:md.index("\n}\n", a) + 2]
+    assert block.split() == gen.rust_block().split()
+    names = re.findall(r"pub fn (dk_[a-z0-9_]+)\(", block)
+    assert sorted(names) == declared_symbols() == sorted(_lib.SYMBOLS)
+    # arity of the ctypes binding against the header
+    for name, ret, params in gen.declarations():
+        assert len(_lib.SYMBOLS[name][1]) == len(params), name
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared_symbols():

@@ -58,9 +58,10 @@ def test_cli_matches_oracle(tmp_path, rng, k, mode):
     km, cn, _ = orc.bloom_probe(f, 22, 4, 4242, k, True, cseq, coff, min_count=2)
     expect = ["kmer\tcount"] + [f"{kmer_str(a['hi'], a['lo'], k)}\t{int(c)}" for a, c in zip(km, cn)]
     assert out.read_text().strip().split("\n") == expect and len(expect) > 5
-    # the saved filter reproduces the run without the parents
+    # the saved filter reproduces the run without the parents -- here with the child streamed in two hash-window passes
     out2 = tmp_path / "out2.tsv"
-    subprocess.run(base + ["--load-filter", str(flt), "--child", str(tmp_path / "c.txt"), "--out", str(out2)],
+    subprocess.run(base + ["--load-filter", str(flt), "--child", str(tmp_path / "c.txt"), "--out", str(out2), "--windows", "2",
+                           "--accum-capacity", "100000"],
                    check=True, capture_output=True, text=True)
     assert out2.read_text() == out.read_text()
     assert np.array_equal(np.fromfile(flt, dtype=np.uint64, offset=64), f)

@@ -113,3 +113,29 @@ def test_two_ranks_exact_set_union_matches_whole_input_oracle(mode, k):
     for rank, table, mhi, mlo, mcnt, n_keys in outs:
         assert n_keys == len(pk)
         assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcnt, cn)
+
+
+def test_native_allreduce_world_one_through_the_abi():
+    """dk_comm_init / dk_set_allreduce_or with one rank: the communicator is accepted, the all-reduce is the
+    identity, a second communicator is refused.  (World sizes above one need one GPU per rank -- RCCL refuses two
+    ranks on one device -- so the native path beyond this runs for the first time in the driver's multi-GPU bench;
+    the slice arithmetic it shares with the torch path is covered by tests/test_dist_gloo.py.)"""
+    import denovo_kmer_amd as d
+    rng = np.random.default_rng(3)
+    reads = ["".join(rng.choice(list("ACGT"), size=120)) for _ in range(200)]
+    for set_kind, bits in (("bloom", 24), ("exact", 26)):
+        with d.Engine(k=31, filter_log2_bits=bits, seed=5, set_kind=set_kind) as eng:
+            ks = d.KmerSet(eng)
+            ks.insert_sequences(reads)
+            before = ks.to_host()
+            assert ks.allreduce_or() == 0                     # no communicator: a no-op
+            eng.comm_init(None, 0, 1)
+            assert ks.allreduce_or() == 0
+            assert np.array_equal(ks.to_host(), before)
+            with pytest.raises(d.DkError):
+                eng.comm_init(None, 0, 1)
+            eng.comm_finalize()
+            eng.comm_init(None, 0, 1)
+            with pytest.raises(d.DkError):
+                eng.comm_init(None, 1, 1)
+            ks.close()

@@ -77,8 +77,8 @@ private:
 };
 
 struct Args {
-    uint32_t k = 31, filter_log2 = 30, hashes = 4, min_count = 1, mode = DK_MODE_AUTO;
-    uint64_t seed = 0x5EED, batch_reads = 2000000;
+    uint32_t k = 31, filter_log2 = 30, hashes = 4, min_count = 1, mode = DK_MODE_AUTO, windows = 1;
+    uint64_t seed = 0x5EED, batch_reads = 2000000, accum_capacity = 64000000;
     bool canonical = true, exact = false;
     std::vector<std::string> parents;
     std::string child, out, save_filter, load_filter;
@@ -88,7 +88,9 @@ struct Args {
 {
     std::fprintf(stderr, "%s\nusage: denovo_kmer_cli --k K --filter-log2 N --parent FILE [--parent FILE ...] --child FILE --out FILE\n"
                          "       [--hashes 4] [--seed N] [--min-count 1] [--batch-reads 2000000] [--mode auto|direct|bucketed]\n"
-                         "       [--save-filter FILE] [--load-filter FILE] [--forward-only] [--exact]\n", msg);
+                         "       [--save-filter FILE] [--load-filter FILE] [--forward-only] [--exact]\n"
+                         "       [--windows 1] [--accum-capacity 64000000]   (child-only occurrences expected per hash window;\n"
+                         "        the child file is read once per window)\n", msg);
     std::exit(2);
 }
 
@@ -107,6 +109,8 @@ Args parse(int argc, char **argv)
         else if (f == "--seed") a.seed = std::stoull(val());
         else if (f == "--min-count") a.min_count = (uint32_t)std::stoul(val());
         else if (f == "--batch-reads") a.batch_reads = std::stoull(val());
+        else if (f == "--windows") a.windows = (uint32_t)std::stoul(val());
+        else if (f == "--accum-capacity") a.accum_capacity = std::stoull(val());
         else if (f == "--parent") a.parents.push_back(val());
         else if (f == "--child") a.child = val();
         else if (f == "--out") a.out = val();
@@ -122,6 +126,7 @@ Args parse(int argc, char **argv)
     if (a.child.empty() || a.out.empty()) usage("--child and --out are required");
     if (a.parents.empty() && a.load_filter.empty()) usage("give --parent files or --load-filter");
     if (a.batch_reads == 0) usage("--batch-reads must be positive");
+    if (a.windows == 0 || (a.windows & (a.windows - 1))) usage("--windows must be a power of two");
     return a;
 }
 
@@ -181,16 +186,22 @@ int main(int argc, char **argv)
         if (!a.save_filter.empty()) parents.save(a.save_filter);
         if (a.exact) std::fprintf(stderr, "exact parent set: %llu k-mers\n", (unsigned long long)parents.popcount());
 
-        dk_host::KmerCounter counter(eng);
-        std::vector<dk_result *> tables;
-        const uint64_t n_child = for_each_batch(a.child, a.batch_reads, [&](const std::vector<std::string> &b) {
-            dk_host::ReadBatch rb(eng, b);
-            tables.push_back(counter.child_only_device(rb, parents));
-        });
-        dk_host::KmerCounts res = counter.merge(tables, a.min_count);
-        for (dk_result *t : tables) dk_result_destroy(t);
-        std::fprintf(stderr, "child %s: %llu reads in %zu batch(es); %zu child-only k-mers with count >= %u (%llu distinct)\n",
-                     a.child.c_str(), (unsigned long long)n_child, tables.size(), res.size(), a.min_count,
+        // the child's absent k-mer occurrences stay on the GPU across batches and are counted once per hash window
+        dk_host::ChildAccumulator acc(eng, &parents, a.accum_capacity, a.windows);
+        dk_host::KmerCounts res{};
+        uint64_t n_child = 0, n_batches = 0;
+        for (uint32_t w = 0; w < a.windows; w++) {
+            acc.reset(w);
+            n_batches = 0;
+            n_child = for_each_batch(a.child, a.batch_reads, [&](const std::vector<std::string> &b) {
+                dk_host::ReadBatch rb(eng, b);
+                acc.add(rb);
+                n_batches++;
+            });
+            acc.finish(a.min_count, res);
+        }
+        std::fprintf(stderr, "child %s: %llu reads in %llu batch(es), %u hash window(s); %zu child-only k-mers with count >= %u (%llu distinct)\n",
+                     a.child.c_str(), (unsigned long long)n_child, (unsigned long long)n_batches, a.windows, res.size(), a.min_count,
                      (unsigned long long)res.stats.n_distinct);
 
         std::vector<size_t> order(res.size());
