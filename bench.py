@@ -185,6 +185,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option for A/B runs (dk_engine_set_option), e.g. --opt sweep_variant=1")
     args = ap.parse_args()
 
     import numpy as np  # noqa: F401
@@ -233,6 +235,9 @@ def main():
     gcfg = dk.synth_config(seed=args.seed, genome_len=genome_len, read_len=L, err_rate=wl["err"])
     eng = dk.Engine(k=k, filter_log2_bits=args.log2_bits, n_hashes=args.n_hashes, seed=args.seed,
                     device_id=local_rank, mode=args.mode, rank=rank, world_size=world, set_kind=args.set_kind)
+    for ov in args.opt:
+        name, _, val = ov.partition("=")
+        eng.set_option(name, int(val))
     batch = min(wl["batch"], reads_rank)
     pbatch = min(wl["parent_batch"], reads_rank)
     n_batches = (reads_rank + batch - 1) // batch
@@ -257,15 +262,19 @@ def main():
 
     # ---- parent build (reported, not part of `value`): every batch of both parents ------------------
     insert_ms, insert_windows, insert_stages, t_par = 0.0, 0, {}, time.perf_counter()
-    parent_windows = 0
+    parent_windows, parent_dev_ms, parent_gen_s, parent_batch_ms = 0, 0.0, 0.0, []
     progress("parent build: 2 x %d batches of %d reads into a 2^%d-bit set" % (n_pbatches, pbatch, args.log2_bits))
     for s in (0, 1):
         for b in range(n_pbatches):
             lo, n = batch_range(b, pbatch)
+            tg = time.perf_counter()
             pb = dk.ReadBatch.synth(eng, gcfg, s, lo, n)
+            parent_gen_s += time.perf_counter() - tg
             st = kset.insert_reads(pb)
             t = eng.timings()
             parent_windows += st["n_windows"]
+            parent_dev_ms += t["total_ms"]
+            parent_batch_ms.append(round(t["total_ms"], 2))
             if n == pbatch:                  # rate of a full batch, not the first one (which also grows the workspace pool)
                 insert_ms, insert_windows = t["total_ms"], st["n_windows"]
                 insert_stages = {name: ms for name, ms in t["stages"]}
@@ -465,7 +474,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "k": k, "reads_per_sample": reads_total, "reads_per_gpu": reads_rank,
                        "reads_per_step": batch, "read_len": L, "filter_log2_bits": args.log2_bits, "n_hashes": args.n_hashes,
-                       "mode": args.mode, "set_kind": args.set_kind, "hash_windows": R,
+                       "mode": args.mode, "set_kind": args.set_kind, "hash_windows": R, "engine_options": args.opt,
                        "windows_counted_per_step": "n_windows / hash_windows",
                        "parallelism": "reads sharded x%d, %s-all-reduce of parent set" % (world, "OR" if args.set_kind == "bloom" else "union")},
             "roofline": rl,
@@ -476,6 +485,8 @@ def main():
                              "insert_ms_per_batch": insert_ms, "insert_stages_ms": insert_stages, "batches": 2 * n_pbatches,
                              "reads_per_batch": pbatch,
                              "seconds_all_batches_incl_read_generation": parent_seconds,
+                             "read_generation_seconds": parent_gen_s, "device_ms_of_each_batch": parent_batch_ms, "device_seconds_all_batches": parent_dev_ms * 1e-3,
+                             "gkmers_s_all_batches_device_time": parent_windows / (parent_dev_ms * 1e-3) / 1e9 if parent_dev_ms else None,
                              "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes,
                              "or_allreduce_path": allreduce_path,
                              "or_allreduce_gbs_per_rank": allreduce_bytes / (allreduce_ms * 1e-3) / 1e9 if allreduce_ms else None,

@@ -57,6 +57,7 @@ struct BucketPlan {
     uint64_t n_max;        // upper bound on records of the batch
     int tile;              // positions per scan_part tile
     int variant;           // scan_part geometry (see make_plan)
+    int sbits;             // sub-segment split: every partition region covers 2^sbits 64-KiB segments (PieceList::sbits)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
@@ -660,6 +661,15 @@ struct PieceList {
     // segment s owns extra[extra_off[s] .. extra_off[s + 1])
     const R *extra;
     const uint32_t *extra_off;
+    // Sub-segment split (set kernels only): the list is partitioned into REGIONS of 2^sbits 64-KiB segments; the
+    // workgroup of segment g reads the records of region g >> sbits and takes those whose hash bits at sub_shift
+    // equal g's low sbits.  The last partition bits are thus resolved by 2^sbits workgroups re-reading one region
+    // (mostly from L2 / Infinity Cache) instead of by one more multisplit pass over HBM.
+    int sbits = 0, sub_shift = 0;
+    __device__ __forceinline__ bool mine(uint64_t seg_id, uint64_t h) const
+    {
+        return sbits == 0 || ((uint32_t)(h >> sub_shift) & ((1u << sbits) - 1u)) == ((uint32_t)seg_id & ((1u << sbits) - 1u));
+    }
 };
 
 template <class R>
@@ -732,30 +742,64 @@ __device__ __forceinline__ void load_segment(uint32_t *seg, const unsigned long 
     for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += (int)blockDim.x) dst[i] = src[i];
 }
 
+// Which 64-KiB segment a workgroup of the set kernels takes: simply its block index.  (With a sub-segment split,
+// placing the 2^sbits workgroups that share a region on one XCD -- block indices 8 apart, so that the region's second
+// reading hits that XCD's L2 -- measured slower: seg_probe 13.2 ms against 9.8 ms at 2^39 bits, two hash windows,
+// 24 M reads; consecutive blocks reading consecutive segments spread the sweep evenly over XCDs and channels.)
+__device__ __forceinline__ uint64_t segment_of_block(int, uint64_t) { return blockIdx.x; }
+
+// The three dependent fetches of a segment workgroup -- piece sizes, the 64-KiB segment, the first records -- are
+// issued back to back: the segment travels to registers while the sizes arrive, the first records are requested as
+// soon as the sizes are known, and only then is the segment written to LDS (with two workgroups per CU every
+// exposed round trip to HBM is a third of a workgroup's life).
+constexpr int SEG_VEC = SEG_BYTES / 16 / SEG_THREADS;      // uint4 per thread per segment
+struct SegRegs { uint4 v[SEG_VEC]; };
+
+__device__ __forceinline__ SegRegs fetch_segment(const unsigned long long *filter, uint64_t seg_id)
+{
+    const uint4 *src = (const uint4 *)filter + seg_id * (SEG_BYTES / 16);
+    SegRegs r;
+#pragma unroll
+    for (int q = 0; q < SEG_VEC; q++) r.v[q] = src[q * SEG_THREADS + (int)threadIdx.x];
+    return r;
+}
+
+__device__ __forceinline__ void stage_segment(uint32_t *seg, const SegRegs &r)
+{
+    uint4 *dst = (uint4 *)seg;
+#pragma unroll
+    for (int q = 0; q < SEG_VEC; q++) dst[q * SEG_THREADS + (int)threadIdx.x] = r.v[q];
+}
+
 template <class R>
 __global__ void __launch_bounds__(SEG_THREADS)
 seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
-    const uint64_t seg_id = blockIdx.x;
-    const SegPieces<R> sp = seg_pieces(pl, seg_id);
+    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
+    const SegRegs sr = fetch_segment(filter, seg_id);
+    const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) return;                       // nothing to add: leave the segment untouched
-    load_segment(seg, filter, seg_id);
-    __syncthreads();
     constexpr int UNROLL = 8;
-    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
-        uint64_t h[UNROLL];
-        bool have[UNROLL];
+    uint64_t h[UNROLL];
+    bool have[UNROLL];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
             h[u] = sp.at(have[u] ? i : 0).h;
         }
+    };
+    fetch(0);
+    stage_segment(seg, sr);
+    __syncthreads();
+    for (uint32_t i0 = 0;;) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            if (!have[u]) continue;
+            if (!have[u] || !pl.mine(seg_id, h[u])) continue;
             const uint32_t blk = (uint32_t)(h[u] >> blk_shift) & (SEG_BLOCKS - 1);
             const uint32_t a = (uint32_t)(h[u] & 511), d = (uint32_t)((h[u] >> 9) & 511) | 1u;
             for (int j = 0; j < n_hashes; j++) {
@@ -763,6 +807,9 @@ seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int
                 atomicOr(&seg[blk * 16 + (bit >> 5)], 1u << (bit & 31));
             }
         }
+        i0 += UNROLL * SEG_THREADS;
+        if (i0 >= n) break;
+        fetch(i0);
     }
     __syncthreads();
     uint4 *dst = (uint4 *)filter + seg_id * (SEG_BYTES / 16);
@@ -784,7 +831,8 @@ struct MissOut {
     int sub_bits, sub_shift;
     OvfList<R> ovf;
 };
-constexpr int MAX_SUB_BITS = 6;
+constexpr int MAX_SUB_BITS = 10;
+constexpr int SUB_TALLY = 1 << MAX_SUB_BITS;       // index of the batch's absent tally behind the units' fills
 
 template <class R, bool ACC>
 struct MissSink {
@@ -798,7 +846,7 @@ struct MissSink {
         if constexpr (ACC) {
             dst = m.recs + (seg_local << m.sub_bits) * (uint64_t)m.cap;
             if (threadIdx.x < (1u << m.sub_bits)) sfill[threadIdx.x] = m.cnt[(seg_local << m.sub_bits) + threadIdx.x];
-            if (threadIdx.x == 64) sfill[64] = 0;                          // [64] = absent records of this batch
+            if (threadIdx.x == 0) sfill[SUB_TALLY] = 0;                    // absent records of this batch
         } else {
             dst = m.recs + seg_local * (uint64_t)m.cap;
             if (threadIdx.x == 0) sfill[0] = 0;
@@ -832,13 +880,13 @@ struct MissSink {
     {
         if constexpr (ACC) {
             const uint32_t ws = wave_total(my_absent);
-            if (lane_id() == 0 && ws) atomicAdd(&sfill[64], ws);
-            __syncthreads();
+            if (lane_id() == 0 && ws) atomicAdd(&sfill[SUB_TALLY], ws);
+            lds_barrier();
             if (threadIdx.x < (1u << mo.sub_bits)) {
                 const uint32_t f = sfill[threadIdx.x];
                 mo.cnt[(seg << mo.sub_bits) + threadIdx.x] = f < mo.cap ? f : mo.cap;
             }
-            if (threadIdx.x == 0 && sfill[64]) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)sfill[64]);
+            if (threadIdx.x == 0 && sfill[SUB_TALLY]) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)sfill[SUB_TALLY]);
             n_dropped = (uint32_t)wave_sum(n_dropped);
             if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
         } else {
@@ -858,29 +906,35 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
                  uint64_t seg_base, MissOut<R> mo, Counters *ctr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
-    __shared__ uint32_t sfill[ACC ? 65 : 1];
-    const uint64_t seg_id = blockIdx.x;
-    const SegPieces<R> sp = seg_pieces(pl, seg_id);
+    __shared__ uint32_t sfill[ACC ? SUB_TALLY + 1 : 1];
+    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const bool no_set = filter == nullptr;    // accumulating KmerCounter: every record counts as absent
+    const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
+    SegRegs sr;
+    if (!no_set) sr = fetch_segment(filter, seg_base + seg_id);
+    const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) {
         if (!ACC && threadIdx.x == 0) mo.cnt[seg_id] = 0;
         return;
     }
-    MissSink<R, ACC> sink(sfill, mo, seg_id);
-    const bool no_set = filter == nullptr;    // accumulating KmerCounter: every record counts as absent
-    if (!no_set) load_segment(seg, filter, seg_base + seg_id);
-    __syncthreads();
-    uint32_t my_absent = 0;
     constexpr int UNROLL = 8;                 // records in flight per thread: loads first, then the LDS tests
-    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
-        R rec[UNROLL];
-        bool have[UNROLL];
+    R rec[UNROLL];
+    bool have[UNROLL];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
             rec[u] = sp.at(have[u] ? i : 0);
         }
+    };
+    fetch(0);
+    MissSink<R, ACC> sink(sfill, mo, seg_id);
+    if (!no_set) stage_segment(seg, sr);
+    __syncthreads();
+    uint32_t my_absent = 0;
+    for (uint32_t i0 = 0;;) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint64_t hu = rec[u].h;
@@ -902,13 +956,155 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
                     all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
                 }
             }
-            const bool absent = have[u] && !all;
+            const bool absent = have[u] && !all && pl.mine(seg_id, hu);
             my_absent += absent;
             sink.put(absent, rec[u]);
         }
+        i0 += UNROLL * SEG_THREADS;
+        if (i0 >= n) break;
+        fetch(i0);
     }
     __syncthreads();
     sink.finish(ctr, my_absent);
+}
+
+// ---- persistent sweep: 2 workgroups per CU walk the segments ------------------------------------------------------
+// With 2^19 - 2^20 segments of a few thousand records each (whole-genome sets) a workgroup per segment spends most
+// of its life waiting for its own three round trips to HBM and being launched.  Here a workgroup walks segments
+// blockIdx.x, + gridDim.x, ...: while it tests the records of one segment in LDS, the next segment and its piece
+// sizes are already travelling to its registers; barriers order LDS traffic only (lds_barrier), so they do not
+// wait for those loads.  Same results as the per-segment kernels (tests run both).
+template <class R, int NH, bool ACC>
+__global__ void __launch_bounds__(SEG_THREADS)
+seg_probe_walk_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
+                      uint64_t seg_base, MissOut<R> mo, Counters *ctr, uint64_t n_seg)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
+    __shared__ uint32_t sfill[ACC ? SUB_TALLY + 1 : 1];
+    uint64_t seg_id = blockIdx.x;
+    if (seg_id >= n_seg) return;
+    SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
+    SegRegs sr = fetch_segment(filter, seg_base + seg_id);
+    constexpr int UNROLL = 8;
+    for (;;) {
+        const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
+        const uint32_t n = sp.total();
+        R rec[UNROLL];
+        bool have[UNROLL];
+        auto fetch = [&](uint32_t i0) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
+                have[u] = i < n;
+                rec[u] = sp.at(have[u] ? i : 0);
+            }
+        };
+        fetch(0);
+        MissSink<R, ACC> sink(sfill, mo, seg_id);
+        stage_segment(seg, sr);
+        lds_barrier();
+        const uint64_t next = seg_id + gridDim.x;
+        const bool has_next = next < n_seg;
+        if (has_next) {                       // in flight while this segment is probed
+            sc = seg_counts(pl, next >> pl.sbits);
+            sr = fetch_segment(filter, seg_base + next);
+        }
+        uint32_t my_absent = 0;
+        for (uint32_t i0 = 0;;) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint64_t hu = rec[u].h;
+                const uint32_t blk = (uint32_t)(hu >> blk_shift) & (SEG_BLOCKS - 1);
+                const uint32_t a = (uint32_t)(hu & 511), d = (uint32_t)((hu >> 9) & 511) | 1u;
+                bool all = true;
+                if constexpr (NH > 0) {
+                    uint32_t acc = 1u;
+#pragma unroll
+                    for (int j = 0; j < NH; j++) {
+                        const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                        acc &= seg[blk * 16 + (bit >> 5)] >> (bit & 31);
+                    }
+                    all = acc & 1u;
+                } else {
+                    for (int j = 0; j < n_hashes; j++) {
+                        const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                        all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
+                    }
+                }
+                const bool absent = have[u] && !all && pl.mine(seg_id, hu);
+                my_absent += absent;
+                sink.put(absent, rec[u]);
+            }
+            i0 += UNROLL * SEG_THREADS;
+            if (i0 >= n) break;
+            fetch(i0);
+        }
+        lds_barrier();
+        sink.finish(ctr, my_absent);
+        lds_barrier();                        // seg[] and sfill[] are free for the next segment
+        if (!has_next) break;
+        seg_id = next;
+    }
+}
+
+template <class R>
+__global__ void __launch_bounds__(SEG_THREADS)
+seg_insert_walk_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift, uint64_t n_seg)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
+    uint64_t seg_id = blockIdx.x;
+    if (seg_id >= n_seg) return;
+    SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
+    SegRegs sr = fetch_segment(filter, seg_id);
+    constexpr int UNROLL = 8;
+    for (;;) {
+        const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
+        const uint32_t n = sp.total();
+        uint64_t h[UNROLL];
+        bool have[UNROLL];
+        auto fetch = [&](uint32_t i0) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
+                have[u] = i < n;
+                h[u] = sp.at(have[u] ? i : 0).h;
+            }
+        };
+        fetch(0);
+        stage_segment(seg, sr);
+        lds_barrier();
+        const uint64_t next = seg_id + gridDim.x;
+        const bool has_next = next < n_seg;
+        if (has_next) {
+            sc = seg_counts(pl, next >> pl.sbits);
+            sr = fetch_segment(filter, next);
+        }
+        for (uint32_t i0 = 0;;) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                if (!have[u] || !pl.mine(seg_id, h[u])) continue;
+                const uint32_t blk = (uint32_t)(h[u] >> blk_shift) & (SEG_BLOCKS - 1);
+                const uint32_t a = (uint32_t)(h[u] & 511), d = (uint32_t)((h[u] >> 9) & 511) | 1u;
+                for (int j = 0; j < n_hashes; j++) {
+                    const uint32_t bit = (a + (uint32_t)j * d) & 511;
+                    atomicOr(&seg[blk * 16 + (bit >> 5)], 1u << (bit & 31));
+                }
+            }
+            i0 += UNROLL * SEG_THREADS;
+            if (i0 >= n) break;
+            fetch(i0);
+        }
+        lds_barrier();
+        if (n) {                              // nothing added: the segment in HBM is already right
+            uint4 *dst = (uint4 *)filter + seg_id * (SEG_BYTES / 16);
+            const uint4 *s4 = (const uint4 *)seg;
+#pragma unroll
+            for (int q = 0; q < SEG_VEC; q++) dst[q * SEG_THREADS + (int)threadIdx.x] = s4[q * SEG_THREADS + (int)threadIdx.x];
+        }
+        lds_barrier();                        // every thread has read its part of seg[] back
+        if (!has_next) break;
+        seg_id = next;
+    }
 }
 
 // ---- exact set: the segment is an open-addressing table (dk_device.h) -----------------------------
@@ -920,27 +1116,36 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
     constexpr bool WIDE = sizeof(R) == 16;
     static_assert(SEG_BYTES == EXACT_SEG_WORDS * 8, "exact segments are the filter segments");
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
-    const uint64_t seg_id = blockIdx.x;
-    const SegPieces<R> sp = seg_pieces(pl, seg_id);
+    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
+    const SegRegs sr = fetch_segment(table, seg_id);
+    const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) return;
-    load_segment((uint32_t *)tab, table, seg_id);
-    __syncthreads();
-    const uint64_t EMPTY = exact_empty(seg_id, T);
-    uint32_t n_full = 0;
     constexpr int UNROLL = 8;
-    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
-        R rec[UNROLL];
-        bool have[UNROLL];
+    R rec[UNROLL];
+    bool have[UNROLL];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
             rec[u] = sp.at(have[u] ? i : 0);
         }
+    };
+    fetch(0);
+    stage_segment((uint32_t *)tab, sr);
+    __syncthreads();
+    const uint64_t EMPTY = exact_empty(seg_id, T);
+    uint32_t n_full = 0;
+    for (uint32_t i0 = 0;;) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
-            if (have[u] && exact_insert<WIDE, __HIP_MEMORY_SCOPE_WORKGROUP>(tab, EMPTY, rec[u].h, rec_hi(rec[u])) == 2) n_full++;
+            if (have[u] && pl.mine(seg_id, rec[u].h) &&
+                exact_insert<WIDE, __HIP_MEMORY_SCOPE_WORKGROUP>(tab, EMPTY, rec[u].h, rec_hi(rec[u])) == 2) n_full++;
+        i0 += UNROLL * SEG_THREADS;
+        if (i0 >= n) break;
+        fetch(i0);
     }
     __syncthreads();
     uint4 *dst = (uint4 *)table + seg_id * (SEG_BYTES / 16);
@@ -961,35 +1166,43 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
 {
     constexpr bool WIDE = sizeof(R) == 16;
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
-    __shared__ uint32_t sfill[ACC ? 65 : 1];
-    const uint64_t seg_id = blockIdx.x;
-    const SegPieces<R> sp = seg_pieces(pl, seg_id);
+    __shared__ uint32_t sfill[ACC ? SUB_TALLY + 1 : 1];
+    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
+    const SegRegs sr = fetch_segment(table, seg_base + seg_id);
+    const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) {
         if (!ACC && threadIdx.x == 0) mo.cnt[seg_id] = 0;
         return;
     }
-    MissSink<R, ACC> sink(sfill, mo, seg_id);
-    load_segment((uint32_t *)tab, table, seg_base + seg_id);
-    __syncthreads();
-    const uint64_t EMPTY = exact_empty(seg_base + seg_id, T);
-    uint32_t my_absent = 0;
     constexpr int UNROLL = 8;
-    for (uint32_t i0 = 0; i0 < n; i0 += UNROLL * SEG_THREADS) {
-        R rec[UNROLL];
-        bool have[UNROLL];
+    R rec[UNROLL];
+    bool have[UNROLL];
+    auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
             rec[u] = sp.at(have[u] ? i : 0);
         }
+    };
+    fetch(0);
+    MissSink<R, ACC> sink(sfill, mo, seg_id);
+    stage_segment((uint32_t *)tab, sr);
+    __syncthreads();
+    const uint64_t EMPTY = exact_empty(seg_base + seg_id, T);
+    uint32_t my_absent = 0;
+    for (uint32_t i0 = 0;;) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            const bool absent = have[u] && !exact_find<WIDE>(tab, EMPTY, rec[u].h, rec_hi(rec[u]));
+            const bool absent = have[u] && pl.mine(seg_id, rec[u].h) && !exact_find<WIDE>(tab, EMPTY, rec[u].h, rec_hi(rec[u]));
             my_absent += absent;
             sink.put(absent, rec[u]);
         }
+        i0 += UNROLL * SEG_THREADS;
+        if (i0 >= n) break;
+        fetch(i0);
     }
     __syncthreads();
     sink.finish(ctr, my_absent);
@@ -1475,12 +1688,29 @@ inline int count_segments_log2(const dk_engine *e, uint64_t n_records)
 
 inline int set_segment_bits(const dk_engine *e) { return (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS; }
 
+// Sub-segment split: with 2^19 segments to route to (a 2^38-bit set, or one of two hash windows of a 2^39-bit one) two
+// multisplit levels reach 2^18 regions and the segment kernels take the last bit, which saves the third pass over
+// the records (16 bytes per record of HBM traffic) for one re-read of a region by the workgroup of the sibling
+// segment.  Option "sub_split": 0 = this rule, 1..3 = force, 9 = never.
+inline int pick_sub_bits(const dk_engine *e, int T_local)
+{
+    const int o = e->opt.sub_split;
+    if (o == 9) return 0;
+    if (o >= 1 && o <= 3) return T_local - o >= 1 ? o : 0;
+    // (one bit only: four workgroups re-reading a region cost seg_insert more than the third pass -- 50.7 vs 34.8 + 19.7 ms
+    // per 48 M reads at 2^39 bits)
+    return T_local == 2 * MAX_BIN_BITS + 1 ? 1 : 0;
+}
+
 // T_override > 0: number of segment bits to use instead of the filter's.  wbits > 0: only the records of one
 // hash window (1 / 2^wbits of them) are partitioned, over the T - wbits segment bits below the window's.
-inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0, int wbits = 0)
+// sbits > 0 (insert / accumulate against a set): the partition stops sbits bits short of the 64-KiB segments, the segment
+// kernels resolve them (PieceList::sbits); p->T, n_seg, cap2 then describe the regions.
+inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0, int wbits = 0, int sbits = 0)
 {
     const bool wide = e->cfg.k > 32;
-    p->T = (T_override > 0 ? T_override : set_segment_bits(e)) - wbits;
+    p->sbits = sbits;
+    p->T = (T_override > 0 ? T_override : set_segment_bits(e)) - wbits - sbits;
     if (p->T < 1 || p->T > MAX_SEG_BITS) return false;
     p->b3 = 0;
     p->capA = 0;
@@ -1708,6 +1938,15 @@ inline dk_status sync_counters(dk_engine *e, const char *what)
     return DK_OK;
 }
 
+// Option "sweep_variant": 1 = one workgroup per segment, 2 = persistent walk, 0 = automatic: the walk for seg_insert
+// from 2^19 segments on (34.9 -> 32.7 ms per 48 M reads at 2^39 bits), never for the probe (9.8 -> 12.8 ms there: the
+// hardware's workgroup scheduler overlaps the short probe phases better than two resident walkers per CU do)
+inline bool sweep_walks(const dk_engine *e, uint64_t n_seg, bool insert)
+{
+    if (e->opt.sweep_variant) return e->opt.sweep_variant == 2;
+    return insert && n_seg >= (1ULL << 19);
+}
+
 // Returns DK_ERR_OVERFLOW when even the overflow list overflowed: the caller then runs the direct
 // family on the whole batch, which is exact (OR is idempotent, records already inserted do no harm).
 template <bool WIDE>
@@ -1715,23 +1954,30 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
 {
     using R = typename RecOf<WIDE>::type;
     BucketPlan p;
-    if (!make_plan(e, r, &p)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
+    const int T_full = set_segment_bits(e);
+    if (!make_plan(e, r, &p, 0, 0, pick_sub_bits(e, T_full))) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B, 0, 0, false);
     if (st == DK_OK) {
-        const PieceList<R> pl{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
+        PieceList<R> pl{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
+        pl.sbits = p.sbits;
+        pl.sub_shift = 64 - T_full;
+        const unsigned n_seg = (unsigned)(p.n_seg << p.sbits);
         if (s->exact)
-            seg_exact_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, p.T, e->d_ctr);
+            seg_exact_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, T_full, e->d_ctr);
+        else if (sweep_walks(e, n_seg, true))
+            seg_insert_walk_kernel<R><<<std::min<unsigned>(n_seg, (unsigned)e->n_cu * 2), SEG_THREADS, 0, e->stream>>>(
+                s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS, n_seg);
         else
-            seg_insert_kernel<R><<<(unsigned)p.n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, pl, (int)e->cfg.n_hashes, 64 - p.T - SEG_LOG2_BLOCKS);
+            seg_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(
+                s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS);
         hipError_t h = hipGetLastError();
         if (h == hipSuccess) {
             stage_mark(e, s->exact ? "seg_exact_insert" : "seg_insert");
             // overflow records (normally none): the kernel reads their number from device memory
             const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
             ovf_insert_kernel<R><<<e->n_cu * 2, DIRECT_BLOCK, 0, e->stream>>>(
-                s->d_words, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes, s->exact ? p.T : 0, e->d_ctr);
+                s->d_words, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes, s->exact ? T_full : 0, e->d_ctr);
             h = hipGetLastError();
         }
         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_insert launch failed: %s", hipGetErrorString(h));
@@ -1749,6 +1995,16 @@ inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &
                                    uint64_t seg_base, const MissOut<R> &mo)
 {
     const int blk_shift = 64 - T_full - SEG_LOG2_BLOCKS;
+    if (!(s && s->exact) && sweep_walks(e, n_seg, false)) {
+        // persistent walk (Bloom sets with many small segments)
+        const unsigned grid = (unsigned)std::min<uint64_t>(n_seg, (uint64_t)e->n_cu * 2);
+        if (s && e->cfg.n_hashes == 4)
+            seg_probe_walk_kernel<R, 4, ACC><<<grid, SEG_THREADS, 0, e->stream>>>(s->d_words, list, 4, blk_shift, seg_base, mo, e->d_ctr, n_seg);
+        else
+            seg_probe_walk_kernel<R, 0, ACC><<<grid, SEG_THREADS, 0, e->stream>>>(
+                s ? s->d_words : nullptr, list, s ? (int)e->cfg.n_hashes : 0, blk_shift, seg_base, mo, e->d_ctr, n_seg);
+        return hipGetLastError();
+    }
     if (s && s->exact)
         seg_exact_probe_kernel<R, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, T_full, seg_base, mo, e->d_ctr);
     else if (s && e->cfg.n_hashes == 4)
@@ -1989,17 +2245,20 @@ inline dk_status bucketed_accum_add_t(dk_engine *e, dk_accum *a, const dk_reads 
     using R = typename RecOf<WIDE>::type;
     *appended = false;
     BucketPlan p;
-    if (!make_plan(e, r, &p, a->T, a->wbits)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
+    const int sbits = a->s ? pick_sub_bits(e, a->T - a->wbits) : 0;
+    if (!make_plan(e, r, &p, a->T, a->wbits, sbits)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B, a->wbits, a->widx, false);
     // nothing may be appended from a batch whose partition lost records: look before the membership kernel runs
     if (st == DK_OK) st = sync_counters(e, "bucketed partition");
     if (st != DK_OK) { free_bufs(e, B); return st; }
-    const PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
+    PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
+    list.sbits = p.sbits;
+    list.sub_shift = 64 - a->T;
     const MissOut<R> mo = accum_out<R>(e, a);
     const uint64_t seg_base = (uint64_t)a->widx << (a->T - a->wbits);
     *appended = true;
-    hipError_t h = launch_seg_probe<R, true>(e, a->s, list, p.n_seg, a->T, seg_base, mo);
+    hipError_t h = launch_seg_probe<R, true>(e, a->s, list, p.n_seg << p.sbits, a->T, seg_base, mo);
     if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
     else stage_mark(e, a->s && a->s->exact ? "seg_exact_probe" : a->s ? "seg_probe" : "seg_append");
     // overflow records of the partition (normally none): probe one by one, append the absent ones through global cursors

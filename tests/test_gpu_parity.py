@@ -641,6 +641,41 @@ def test_scan_part_tile_shapes_agree_with_the_oracle(scan_variant, repart_varian
     _forced_geometry_trio({"scan_variant": scan_variant, "repart_variant": repart_variant}, ["scan_part", "repart"])
 
 
+@pytest.mark.parametrize("sub_split", [1, 2, 3])
+def test_sub_segment_split_of_the_insert_kernels(sub_split):
+    """sub_split forces what 2^38 / 2^39-bit sets do by themselves: the partition stops 1-3 bits short of the 64-KiB
+    segments and 2-8 workgroups share a region, each taking the records of its own segment"""
+    _forced_geometry_trio({"sub_split": sub_split}, ["scan_part", "repart"])
+    d = dk()
+    rng = np.random.default_rng(77)
+    parents, child = related_trio(rng, genome_len=20000, n_reads=500, read_len=120)
+    pseq, poff = orc.concat_reads(parents)
+    cseq, coff = orc.concat_reads(child)
+    km, cn, ost = orc.exact_child_only(45, True, pseq, poff, cseq, coff, 1)
+    with d.Engine(k=45, filter_log2_bits=26, seed=7, mode="bucketed", set_kind="exact") as eng:
+        eng.set_option("sub_split", sub_split)
+        ks, _, res = gpu_trio(eng, parents, child)
+        assert_result_equals(res, km, cn)
+
+
+@pytest.mark.parametrize("options", [{"sweep_variant": 2}, {"sweep_variant": 2, "sub_split": 1}, {"sweep_variant": 1}])
+def test_persistent_walk_of_the_set_kernels(options):
+    """sweep_variant 2 forces the persistent, software-pipelined seg_insert / seg_probe that sets of 2^19 segments and
+    more use by themselves (sweep_variant 1: one workgroup per segment everywhere)"""
+    _forced_geometry_trio(options, ["scan_part", "repart"])
+    d = dk()
+    rng = np.random.default_rng(5)
+    parents, child = related_trio(rng, genome_len=30000, n_reads=900, read_len=140)
+    f, ist, km, cn, pst = oracle_trio(parents, child, 31, 20, 3, 7)      # two segments, 1 workgroup each, many records
+    with d.Engine(k=31, filter_log2_bits=20, n_hashes=3, seed=7, mode="bucketed") as eng:
+        for name, value in options.items():
+            if name != "sub_split":
+                eng.set_option(name, value)
+        ks, _, res = gpu_trio(eng, parents, child)
+        assert np.array_equal(ks.to_host(), f)
+        assert_result_equals(res, km, cn)
+
+
 def test_forced_scan_shape_with_fewer_threads_than_bins():
     """variants 4 / 5 have 256 / 128 threads; with more level-1 bins than threads the plan moves bits to level 2
     (2^33 bits = 2^14 segments: b1_up pushes the level-1 split to 9 bits = 512 bins)"""
@@ -732,7 +767,8 @@ def test_three_level_partition_forced_on_small_inputs():
 
 @pytest.mark.parametrize("set_kind", ["bloom", "exact"])
 def test_three_level_partition_at_2_to_the_38_bits(set_kind):
-    """A 32-GiB parent set (2^19 segments): the bucketed family partitions in three levels; the direct family,
+    """A 32-GiB parent set (2^19 segments): the bucketed family inserts through two levels + the sub-segment split and
+    probes a single batch through three levels; the direct family,
     an independent implementation working on the same geometry, must agree on the set size and on every
     child-only k-mer and count (the oracle cannot hold a 32-GiB filter in this test's time)."""
     d = dk()
@@ -746,7 +782,8 @@ def test_three_level_partition_at_2_to_the_38_bits(set_kind):
                 ks.insert_reads(d.ReadBatch.synth(eng, gcfg, smp, 0, n_reads))
             names = [n for n, _ in eng.timings()["stages"]]
             if mode == "bucketed":
-                assert names[:3] == ["scan_part", "repart", "repart3"], names
+                # 2^19 segments: two partition levels to 2^18 regions, the insert kernel of each segment takes its half
+                assert names[:2] == ["scan_part", "repart"] and "repart3" not in names, names
             else:
                 assert names == ["insert_direct"], names
             pop = ks.popcount()

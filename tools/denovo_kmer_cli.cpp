@@ -187,7 +187,9 @@ int main(int argc, char **argv)
         if (a.exact) std::fprintf(stderr, "exact parent set: %llu k-mers\n", (unsigned long long)parents.popcount());
 
         // the child's absent k-mer occurrences stay on the GPU across batches and are counted once per hash window
-        dk_host::ChildAccumulator acc(eng, &parents, a.accum_capacity, a.windows);
+        // (what one hash window of this set geometry can count: 1024 units of 12288 (k > 32: 6144) records per 64-KiB segment)
+        const uint64_t geometry_max = (1ULL << (a.filter_log2 - 19)) / a.windows * 1024 * (a.k > 32 ? 6144 : 12288);
+        dk_host::ChildAccumulator acc(eng, &parents, std::min<uint64_t>(a.accum_capacity, geometry_max), a.windows);
         dk_host::KmerCounts res{};
         uint64_t n_child = 0, n_batches = 0;
         for (uint32_t w = 0; w < a.windows; w++) {
