@@ -119,6 +119,9 @@ SYMBOLS = {
     "dk_accum_finish": (C.c_int32, [_P, C.c_uint32, _PP, C.POINTER(DkStats)]),
     "dk_accum_reset": (C.c_int32, [_P, C.c_uint32]),
     "dk_accum_stats": (C.c_int32, [_P, C.POINTER(DkStats)]),
+    "dk_accum_geometry": (C.c_int32, [_P, _PU64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "dk_accum_device_view": (C.c_int32, [_P, _PP, _PP, _PP, _PU64]),
+    "dk_accum_finish_pieces": (C.c_int32, [_P, _P, _P, C.c_uint32, _U64, _U64, _P, _U64, C.c_uint32, _PP, C.POINTER(DkStats)]),
     "dk_accum_device_bytes": (C.c_int32, [_P, _PU64]),
     "dk_accum_destroy": (None, [_P]),
 }

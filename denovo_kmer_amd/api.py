@@ -451,6 +451,27 @@ class ChildAccumulator:
     def reset(self, window_index=0):
         self.engine.check(self.engine._lib.dk_accum_reset(self._h, window_index))
 
+    def geometry(self):
+        """-> (units of the window, records per unit, bytes per record)"""
+        n, cap, rb = C.c_uint64(), C.c_uint32(), C.c_uint32()
+        self.engine.check(self.engine._lib.dk_accum_geometry(self._h, C.byref(n), C.byref(cap), C.byref(rb)))
+        return int(n.value), int(cap.value), int(rb.value)
+
+    def device_view(self):
+        """-> (store pointer, fill pointer, overflow-list pointer, overflow entries); synchronises the engine"""
+        st, fl, ov, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self.engine.check(self.engine._lib.dk_accum_device_view(self._h, C.byref(st), C.byref(fl), C.byref(ov), C.byref(n)))
+        return st.value, fl.value, ov.value, int(n.value)
+
+    def finish_pieces(self, stores_ptr, fills_ptr, n_pieces, first_unit, n_units, extra_ptr=0, n_extra=0, min_count=1, keepalive=None):
+        """multi-GPU: count units [first_unit, first_unit + n_units) from the piece-major slices the ranks exchanged"""
+        h = C.c_void_p()
+        st = DkStats()
+        self.engine.check(self.engine._lib.dk_accum_finish_pieces(
+            self._h, C.c_void_p(stores_ptr), C.c_void_p(fills_ptr), n_pieces, first_unit, n_units,
+            C.c_void_p(extra_ptr) if extra_ptr else None, n_extra, min_count, C.byref(h), C.byref(st)))
+        return KmerCounts(self.engine, h, st.as_dict())
+
     def stats(self):
         st = DkStats()
         self.engine.check(self.engine._lib.dk_accum_stats(self._h, C.byref(st)))

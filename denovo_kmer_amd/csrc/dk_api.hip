@@ -350,33 +350,58 @@ static dk_status accum_add_direct(dk_engine *e, dk_accum *a, const dk_reads *r)
     return st;
 }
 
+// Count an accumulator's units.  Single GPU: its own store.  Multi-GPU (pieces != nullptr): the units
+// [first_unit, first_unit + n_units) of the window from n_pieces slices in piece-major order -- what the ranks sent
+// this rank for its share of the hash space -- plus `extra`, the gathered overflow lists (records of other ranks'
+// shares are skipped).
 template <bool WIDE>
-static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, dk_result *res)
+static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, dk_result *res, const void *pieces,
+                                const uint32_t *piece_fills, uint32_t n_pieces, uint64_t first_unit, uint64_t n_units,
+                                const void *extra_in, uint64_t n_extra_in, uint64_t *n_records_out)
 {
     using R = typename RecOf<WIDE>::type;
     const int Tu = accum_unit_bits(a);
-    const uint64_t unit_base = accum_unit_base(a);
+    const uint64_t unit_base = accum_unit_base(a) + first_unit;
     PieceList<R> list{(const R *)a->store, a->fill, 1, a->unit_cap, nullptr, nullptr};
-    // occurrences that found their unit full: sorted by unit (CSR) and counted with it
+    const R *ovf_recs = (const R *)a->ovf;
     unsigned long long n_aovf = 0;
-    DK_HIP(e, hipMemcpyAsync(&n_aovf, a->d_novf, 8, hipMemcpyDeviceToHost, e->stream));
-    DK_HIP(e, hipStreamSynchronize(e->stream));
-    if (n_aovf > a->ovf_cap) n_aovf = a->ovf_cap;
+    uint64_t n_records = a->n_absent;
+    if (pieces) {
+        list = PieceList<R>{(const R *)pieces, piece_fills, n_pieces, a->unit_cap, nullptr, nullptr};
+        list.n_segs = n_units;
+        ovf_recs = (const R *)extra_in;
+        n_aovf = n_extra_in;
+        // the records these pieces hold (sizes the table)
+        DK_HIP(e, hipMemsetAsync(&e->d_ctr->dbg[0], 0, 8, e->stream));
+        fill_sum_kernel<<<grid_for(e, n_pieces * n_units, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+            piece_fills, n_pieces * n_units, a->unit_cap, &e->d_ctr->dbg[0]);
+        DK_HIP(e, hipGetLastError());
+        unsigned long long sum = 0;
+        DK_HIP(e, hipMemcpyAsync(&sum, &e->d_ctr->dbg[0], 8, hipMemcpyDeviceToHost, e->stream));
+        DK_HIP(e, hipStreamSynchronize(e->stream));
+        n_records = sum + n_aovf;
+    } else {
+        // occurrences that found their unit full: sorted by unit (CSR) and counted with it
+        DK_HIP(e, hipMemcpyAsync(&n_aovf, a->d_novf, 8, hipMemcpyDeviceToHost, e->stream));
+        DK_HIP(e, hipStreamSynchronize(e->stream));
+        if (n_aovf > a->ovf_cap) n_aovf = a->ovf_cap;
+    }
+    if (n_records_out) *n_records_out = n_records;
     R *extra = nullptr;
     uint32_t *idx = nullptr;
     dk_status st = DK_OK;
     if (n_aovf) {
         st = pool_alloc(e, n_aovf * sizeof(R), (void **)&extra);
-        if (st == DK_OK) st = pool_alloc(e, (3 * a->n_units + 1) * 4, (void **)&idx);
+        if (st == DK_OK) st = pool_alloc(e, (3 * n_units + 1) * 4, (void **)&idx);
         hipError_t h = hipSuccess;
         if (st == DK_OK) {
-            uint32_t *hist = idx, *off = hist + a->n_units, *fill = off + a->n_units + 1;
-            h = hipMemsetAsync(idx, 0, (3 * a->n_units + 1) * 4, e->stream);
+            uint32_t *hist = idx, *off = hist + n_units, *fill = off + n_units + 1;
+            h = hipMemsetAsync(idx, 0, (3 * n_units + 1) * 4, e->stream);
             if (h == hipSuccess) {
-                unit_hist_kernel<R><<<grid_for(e, n_aovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>((const R *)a->ovf, n_aovf, Tu, unit_base, hist);
-                ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)a->n_units);
+                unit_hist_kernel<R><<<grid_for(e, n_aovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(ovf_recs, n_aovf, Tu, unit_base, hist, n_units);
+                ovf_scan_kernel<<<1, 1024, 0, e->stream>>>(hist, off, (uint32_t)n_units);
                 ovf_scatter_kernel<R><<<grid_for(e, n_aovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                    (const R *)a->ovf, n_aovf, Tu, unit_base, off, fill, extra);
+                    ovf_recs, n_aovf, Tu, unit_base, off, fill, extra, n_units);
                 h = hipGetLastError();
             }
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "accumulator overflow sort failed: %s", hipGetErrorString(h));
@@ -386,7 +411,7 @@ static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, d
         }
     }
     if (st == DK_OK)
-        st = bucketed_count_stage<WIDE>(e, list, a->n_units, Tu, unit_base, a->n_absent, n_aovf, min_count, res);
+        st = bucketed_count_stage<WIDE>(e, list, n_units, Tu, unit_base, n_records, n_aovf, min_count, res);
     pool_free(e, extra);
     pool_free(e, idx);
     return st;
@@ -1515,7 +1540,8 @@ dk_status dk_accum_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_s
     if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
     memset(e->h_ctr, 0, sizeof(Counters));
     stage_begin(e);
-    dk_status st = a->wide ? accum_finish_t<true>(e, a, min_count, res) : accum_finish_t<false>(e, a, min_count, res);
+    dk_status st = a->wide ? accum_finish_t<true>(e, a, min_count, res, nullptr, nullptr, 0, 0, a->n_units, nullptr, 0, nullptr)
+                           : accum_finish_t<false>(e, a, min_count, res, nullptr, nullptr, 0, 0, a->n_units, nullptr, 0, nullptr);
     if (st == DK_OK) st = stage_end(e);
     if (st != DK_OK) { dk_result_destroy(res); return st; }
     if (stats) {
@@ -1525,6 +1551,67 @@ dk_status dk_accum_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_s
         stats->n_windows = a->n_windows;
         stats->n_valid = a->n_valid;
         stats->n_absent = a->n_absent;
+        stats->n_distinct = e->h_ctr->n_distinct;
+        stats->n_emitted = res->n;
+    }
+    *out = res;
+    return DK_OK;
+}
+
+dk_status dk_accum_geometry(const dk_accum *a, uint64_t *n_units, uint32_t *unit_cap, uint32_t *record_bytes)
+{
+    if (!a) return DK_ERR_INVALID_ARG;
+    if (n_units) *n_units = a->n_units;
+    if (unit_cap) *unit_cap = a->unit_cap;
+    if (record_bytes) *record_bytes = (uint32_t)(a->wide ? sizeof(Rec2) : sizeof(Rec1));
+    return DK_OK;
+}
+
+dk_status dk_accum_device_view(dk_accum *a, void **d_store, void **d_fill, void **d_overflow, uint64_t *n_overflow)
+{
+    if (!a) return DK_ERR_INVALID_ARG;
+    dk_engine *e = a->e;
+    if (a->failed) return fail(e, DK_ERR_OVERFLOW, "the accumulator lost records in an earlier call: dk_accum_reset it first");
+    DK_HIP(e, hipSetDevice(e->device));
+    unsigned long long n = 0;
+    DK_HIP(e, hipMemcpyAsync(&n, a->d_novf, 8, hipMemcpyDeviceToHost, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));           // also: every dk_accum_add has landed in the store
+    if (d_store) *d_store = a->store;
+    if (d_fill) *d_fill = a->fill;
+    if (d_overflow) *d_overflow = a->ovf;
+    if (n_overflow) *n_overflow = n > a->ovf_cap ? a->ovf_cap : n;
+    return DK_OK;
+}
+
+dk_status dk_accum_finish_pieces(dk_accum *a, const void *d_stores, const void *d_fills, uint32_t n_pieces,
+                                 uint64_t first_unit, uint64_t n_units, const void *d_extra, uint64_t n_extra,
+                                 uint32_t min_count, dk_result **out, dk_stats *stats)
+{
+    if (!a) return DK_ERR_INVALID_ARG;
+    dk_engine *e = a->e;
+    CHECK_ARG(e, out != nullptr && min_count >= 1);
+    *out = nullptr;
+    CHECK_ARG(e, d_stores != nullptr && d_fills != nullptr);
+    CHECK_ARG(e, n_pieces >= 1 && n_pieces <= (uint32_t)MAX_R);
+    CHECK_ARG(e, n_units >= 1 && first_unit + n_units <= a->n_units);
+    CHECK_ARG(e, d_extra != nullptr || n_extra == 0);
+    DK_HIP(e, hipSetDevice(e->device));
+    dk_result *res = result_new(e);
+    if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
+    hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+    if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
+    memset(e->h_ctr, 0, sizeof(Counters));
+    stage_begin(e);
+    uint64_t n_records = 0;
+    dk_status st = a->wide ? accum_finish_t<true>(e, a, min_count, res, d_stores, (const uint32_t *)d_fills, n_pieces, first_unit,
+                                                  n_units, d_extra, n_extra, &n_records)
+                           : accum_finish_t<false>(e, a, min_count, res, d_stores, (const uint32_t *)d_fills, n_pieces, first_unit,
+                                                   n_units, d_extra, n_extra, &n_records);
+    if (st == DK_OK) st = stage_end(e);
+    if (st != DK_OK) { dk_result_destroy(res); return st; }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_absent = n_records;
         stats->n_distinct = e->h_ctr->n_distinct;
         stats->n_emitted = res->n;
     }

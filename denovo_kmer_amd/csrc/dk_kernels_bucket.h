@@ -37,7 +37,7 @@ constexpr int CURSOR_STRIDE = 32;                      // level-1 cursors on sep
 constexpr int SEG_THREADS = 1024;
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
-constexpr int MAX_R = 4;                               // level-2 producer groups per coarse bin
+constexpr int MAX_R = 8;                               // pieces per counting unit: adjacent segments counted together, or the ranks of a multi-GPU run
 
 // Level-1 buckets are built from PRIVATE pieces, so the scan needs no global atomics at all:
 //   level 1: workgroup w of scan_part owns piece (bin b, w) = a[(b*G + w) * capw ...]
@@ -666,6 +666,9 @@ struct PieceList {
     // equal g's low sbits.  The last partition bits are thus resolved by 2^sbits workgroups re-reading one region
     // (mostly from L2 / Infinity Cache) instead of by one more multisplit pass over HBM.
     int sbits = 0, sub_shift = 0;
+    // Piece-major layout (the receiving side of a multi-GPU exchange: n_pieces slices, one per rank, each holding the
+    // same n_segs units): piece r of segment s = recs[(r * n_segs + s) * piece_cap ...], cnt[r * n_segs + s].  0 = segment-major.
+    uint64_t n_segs = 0;
     __device__ __forceinline__ bool mine(uint64_t seg_id, uint64_t h) const
     {
         return sbits == 0 || ((uint32_t)(h >> sub_shift) & ((1u << sbits) - 1u)) == ((uint32_t)seg_id & ((1u << sbits) - 1u));
@@ -676,7 +679,7 @@ template <class R>
 struct SegPieces {
     uint32_t start[MAX_R + 1];     // prefix sums of the piece sizes; start[MAX_R] = records in the pieces
     const R *base;                 // first piece of the segment
-    uint32_t piece_cap;
+    uint64_t piece_stride;         // records between two pieces of the segment
     const R *extra;                // extra records of the segment (or nullptr)
     uint32_t n_extra;
     __device__ __forceinline__ uint32_t total() const { return start[MAX_R] + n_extra; }
@@ -687,7 +690,7 @@ struct SegPieces {
 #pragma unroll
         for (int q = 1; q < MAX_R; q++)
             if (i >= start[q]) { r = (uint32_t)q; st = start[q]; }     // starts are non-decreasing
-        return base[(uint64_t)r * piece_cap + (i - st)];
+        return base[(uint64_t)r * piece_stride + (i - st)];
     }
 };
 
@@ -702,7 +705,8 @@ __device__ __forceinline__ SegCounts seg_counts(const PieceList<R> &pl, uint64_t
 {
     SegCounts sc;
 #pragma unroll
-    for (int q = 0; q < MAX_R; q++) sc.c[q] = (uint32_t)q < pl.n_pieces ? pl.cnt[seg_id * pl.n_pieces + q] : 0u;
+    for (int q = 0; q < MAX_R; q++)
+        sc.c[q] = (uint32_t)q < pl.n_pieces ? pl.cnt[pl.n_segs ? (uint64_t)q * pl.n_segs + seg_id : seg_id * pl.n_pieces + q] : 0u;
     sc.o0 = sc.o1 = 0;
     if (pl.extra) {
         sc.o0 = pl.extra_off[seg_id];
@@ -715,8 +719,8 @@ template <class R>
 __device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint64_t seg_id, const SegCounts &sc)
 {
     SegPieces<R> sp;
-    sp.base = pl.recs + seg_id * pl.n_pieces * (uint64_t)pl.piece_cap;
-    sp.piece_cap = pl.piece_cap;
+    sp.base = pl.recs + (pl.n_segs ? seg_id : seg_id * pl.n_pieces) * (uint64_t)pl.piece_cap;
+    sp.piece_stride = pl.n_segs ? pl.n_segs * (uint64_t)pl.piece_cap : (uint64_t)pl.piece_cap;
     uint32_t acc = 0;
 #pragma unroll
     for (int q = 0; q < MAX_R; q++) {
@@ -1561,12 +1565,13 @@ ovf_scan_kernel(const uint32_t *__restrict__ hist, uint32_t *__restrict__ off, u
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 ovf_scatter_kernel(const R *__restrict__ miss, uint64_t n, int T, uint64_t unit_base, const uint32_t *__restrict__ off,
-                   uint32_t *fill, R *__restrict__ extra)
+                   uint32_t *fill, R *__restrict__ extra, uint64_t n_units = ~0ULL)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const R rec = miss[i];
         const uint64_t seg = (rec.h >> (64 - T)) - unit_base;
+        if (seg >= n_units) continue;                   // another rank's hash range
         extra[off[seg] + atomicAdd(&fill[seg], 1u)] = rec;
     }
 }
@@ -1575,11 +1580,24 @@ ovf_scatter_kernel(const R *__restrict__ miss, uint64_t n, int T, uint64_t unit_
 // histogram of a record list over the accumulator's units (CSR build of its overflow list at finish)
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
-unit_hist_kernel(const R *__restrict__ recs, uint64_t n, int T, uint64_t unit_base, uint32_t *hist)
+unit_hist_kernel(const R *__restrict__ recs, uint64_t n, int T, uint64_t unit_base, uint32_t *hist, uint64_t n_units)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        atomicAdd(&hist[(recs[i].h >> (64 - T)) - unit_base], 1u);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t u = (recs[i].h >> (64 - T)) - unit_base;
+        if (u < n_units) atomicAdd(&hist[u], 1u);       // else: another rank's hash range
+    }
+}
+
+// sum over units of min(fill, cap): the records a piece list holds
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+fill_sum_kernel(const uint32_t *__restrict__ fill, uint64_t n, uint32_t cap, unsigned long long *out)
+{
+    uint64_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += fill[i] < cap ? fill[i] : cap;
+    acc = wave_sum(acc);
+    if (lane_id() == 0 && acc) atomicAdd(out, (unsigned long long)acc);
 }
 
 // append records (all of them absent, all inside the window) to their units: the absent overflow records of a batch
@@ -1988,6 +2006,10 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     return st;
 }
 
+// (Sub-segment split: one workgroup per REGION that keeps the region's records in registers and stages the sibling
+// segments one after the other reads the records once -- 47 GB instead of 59 GB per launch at 2^39 bits, two hash
+// windows -- and still measured slower than sibling workgroups, 12.0 vs 9.6 ms: with two workgroups per CU, many short
+// independent workgroups overlap their load / probe phases better than fewer, longer ones.)
 // the membership kernel of one batch over the n_seg segments from seg_base on (the set's kind and hash count pick the
 // instance); s == nullptr is only valid with ACC: every record is absent
 template <class R, bool ACC>

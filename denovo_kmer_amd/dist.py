@@ -91,6 +91,76 @@ def or_allreduce_(filt, or_fn, group=None, stage_through_cpu=False):
     return 2 * (world - 1) * sl * filt.element_size()
 
 
+class _DeviceMemory:
+    """library-owned device memory seen by torch through the CUDA array interface (no copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _device_bytes(ptr, nbytes, device):
+    return torch.as_tensor(_DeviceMemory(ptr, nbytes), device=device)
+
+
+def accum_exchange_finish(acc, min_count=1, group=None, stage_through_cpu=False):
+    """Multi-GPU end of a child pass: every rank has accumulated ITS child reads (ChildAccumulator.add) over the same
+    hash window; the ranks now swap unit ranges -- all_to_all_single of the stores and of the fill counters: rank r
+    receives units [r u/P, (r+1) u/P) of every rank -- and each rank counts its own range from the P pieces
+    (dk_accum_finish_pieces).  The returned KmerCounts holds the child-only k-mers of this rank's share of the hash
+    space with counts summed over ALL ranks' reads, min_count applied to the sums; the ranks' tables are disjoint and
+    their union is the answer, so nothing is ever gathered on one GPU.  The (rare) overflow lists are all-gathered.
+    stage_through_cpu: move the payloads through host memory (gloo rehearsal on one GPU)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return acc.finish(min_count=min_count)
+    rank = dist.get_rank(group)
+    eng = acc.engine
+    dev = torch.device("cuda", eng.device_id)
+    n_units, cap, rb = acc.geometry()
+    assert n_units % world == 0, "the units of a window split evenly over a power-of-two number of ranks"
+    upr = n_units // world
+    sp, fp, op, n_ovf = acc.device_view()
+    store = _device_bytes(sp, n_units * cap * rb, dev).view(world, upr * cap * rb)
+    fill = _device_bytes(fp, n_units * 4, dev).view(torch.int32).view(world, upr)
+
+    def a2a(t):
+        if stage_through_cpu:
+            send = t.cpu()
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+            return recv.to(dev)
+        recv = torch.empty_like(t)
+        dist.all_to_all_single(recv, t, group=group)
+        return recv
+
+    recv_fill = a2a(fill)
+    recv_store = a2a(store)
+    # overflow lists: every rank gets all of them and keeps the records of its own unit range
+    sizes = torch.zeros(world, dtype=torch.int64, device="cpu" if stage_through_cpu else dev)
+    sizes[rank] = n_ovf
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+    sizes = [int(x) for x in sizes.cpu()]
+    extra, n_extra = None, sum(sizes)
+    if n_extra:
+        pad = max(sizes)
+        mine = torch.zeros(pad * rb, dtype=torch.uint8, device=dev)
+        if n_ovf:
+            mine[: n_ovf * rb] = _device_bytes(op, n_ovf * rb, dev)
+        if stage_through_cpu:
+            g = torch.empty(world * pad * rb, dtype=torch.uint8)
+            dist.all_gather_into_tensor(g, mine.cpu(), group=group)
+            g = g.to(dev)
+        else:
+            g = torch.empty(world * pad * rb, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(g, mine, group=group)
+        extra = torch.cat([g[r * pad * rb: (r * pad + sizes[r]) * rb] for r in range(world) if sizes[r]])
+    torch.cuda.synchronize()
+    res = acc.finish_pieces(recv_store.data_ptr(), recv_fill.data_ptr(), world, rank * upr, upr,
+                            extra.data_ptr() if extra is not None else 0, n_extra, min_count)
+    res._keep = (recv_store, recv_fill, extra)
+    return res
+
+
 def comm_init_from_torch(engine, group=None):
     """Join `engine` to an RCCL communicator of its own behind the C ABI (dk_comm_init), using torch.distributed
     only to hand rank 0's 128-byte id to the other ranks.  After this KmerSet.allreduce_or() runs the composed

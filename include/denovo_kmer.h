@@ -252,6 +252,23 @@ dk_status dk_accum_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_s
 /* empty the accumulator and move it to another window (same window_count): the next pass over the sample */
 dk_status dk_accum_reset(dk_accum *a, uint32_t window_index);
 dk_status dk_accum_stats(const dk_accum *a, dk_stats *out);     /* totals so far */
+/* Multi-GPU (reads sharded over ranks): every rank accumulates its child shard over the same window, then the ranks
+ * exchange unit ranges so that rank r holds units [r * n_units / P, (r + 1) * n_units / P) of every rank and counts
+ * them -- the result stays sharded by hash range (the ranks' tables are disjoint; their union is the whole answer),
+ * so counts and min_count are exact across the read shards and no rank ever holds the whole table.
+ *   dk_accum_geometry      units of the window, records per unit, bytes per record
+ *   dk_accum_device_view   the store (n_units * unit_cap records, unit-major), the fills (n_units u32, records held by
+ *                          each unit; values above unit_cap mean unit_cap) and the overflow list; synchronises
+ *   dk_accum_finish_pieces counts units [first_unit, first_unit + n_units) from n_pieces (<= 8) slices laid out piece
+ *                          after piece (d_stores: n_pieces * n_units * unit_cap records, d_fills: n_pieces * n_units
+ *                          u32) -- what an all-to-all of the ranks' stores delivers -- plus d_extra, the all-gathered
+ *                          overflow lists (records outside the unit range are skipped).  stats: n_absent = records
+ *                          counted, n_distinct, n_emitted.  denovo_kmer_amd/dist.py:accum_exchange_finish is the recipe. */
+dk_status dk_accum_geometry(const dk_accum *a, uint64_t *n_units, uint32_t *unit_cap, uint32_t *record_bytes);
+dk_status dk_accum_device_view(dk_accum *a, void **d_store, void **d_fill, void **d_overflow, uint64_t *n_overflow);
+dk_status dk_accum_finish_pieces(dk_accum *a, const void *d_stores, const void *d_fills, uint32_t n_pieces,
+                                 uint64_t first_unit, uint64_t n_units, const void *d_extra, uint64_t n_extra,
+                                 uint32_t min_count, dk_result **out, dk_stats *stats);
 /* bytes of device memory the accumulator holds */
 dk_status dk_accum_device_bytes(const dk_accum *a, uint64_t *n_bytes);
 void      dk_accum_destroy(dk_accum *a);

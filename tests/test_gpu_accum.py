@@ -33,7 +33,7 @@ def ragged_batches(reads, cuts):
 
 @pytest.mark.parametrize("mode", ["direct", "bucketed"])
 @pytest.mark.parametrize("k,set_kind,log2_bits", [(31, "bloom", 24), (45, "bloom", 24), (31, "exact", 26), (51, "exact", 26)])
-@pytest.mark.parametrize("window_count,sub_split,sweep", [(1, 0, 0), (4, 0, 2), (1, 2, 0), (2, 1, 2)])
+@pytest.mark.parametrize("window_count,sub_split,sweep", [(1, 0, 0), (4, 0, 2), (1, 2, 0), (2, 1, 2), (2, 1, 1)])
 def test_accumulated_batches_equal_the_whole_sample(mode, k, set_kind, log2_bits, window_count, sub_split, sweep):
     d = dk()
     rng = np.random.default_rng(1234 + k)

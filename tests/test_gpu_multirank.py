@@ -115,6 +115,86 @@ def test_two_ranks_exact_set_union_matches_whole_input_oracle(mode, k):
         assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcnt, cn)
 
 
+def _accum_worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, cap, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import denovo_kmer_amd as dk
+    from denovo_kmer_amd.dist import accum_exchange_finish, local_reduce_fn, or_allreduce_, shard_range
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        gcfg = dk.synth_config(genome_len=100_000)
+        eng = dk.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=nh, seed=seed, device_id=0, mode=mode, rank=rank, world_size=world)
+        filt = torch.zeros((1 << log2_bits) // 64, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        ks = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
+        lo, hi = shard_range(n_reads, rank, world)
+        for s in (0, 1):
+            ks.insert_reads(dk.ReadBatch.synth(eng, gcfg, s, lo, hi - lo))
+        or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=True)
+        out = {}
+        for windows in (1, 2):
+            acc = dk.ChildAccumulator(eng, ks, capacity_records=cap, window_count=windows)
+            for mc in (1, 2):
+                parts = []
+                for w in range(windows):
+                    acc.reset(w)
+                    half = (hi - lo) // 2                     # the rank's shard in two batches
+                    acc.add(dk.ReadBatch.synth(eng, gcfg, 2, lo, half))
+                    acc.add(dk.ReadBatch.synth(eng, gcfg, 2, lo + half, hi - lo - half))
+                    res = accum_exchange_finish(acc, min_count=mc, stage_through_cpu=True)
+                    parts.append(res.to_host(sort=False))
+                    res.close()
+                out[(windows, mc)] = tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+            acc.close()
+        q.put((rank, out))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode,k,cap", [("bucketed", 31, 400_000), ("direct", 45, 400_000), ("bucketed", 31, 1)])
+def test_two_ranks_exchange_accumulators_for_exact_counts_across_shards(mode, k, cap):
+    """every rank accumulates its child shard; the ranks swap unit ranges and count their own share of the hash space
+    from both ranks' pieces: the union of the ranks' tables must be the oracle's table of the WHOLE child, counts and
+    min_count included (cap = 1: nearly everything travels through the all-gathered overflow lists)"""
+    n_reads, log2_bits, nh, seed, world = 6000, 24, 4, 31337, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, n_reads, k, log2_bits, nh, seed, mode, cap, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ocfg = orc.synth_cfg(genome_len=100_000)
+    f = orc.new_filter(log2_bits)
+    for smp in (0, 1):
+        seq, off = orc.synth_reads(ocfg, smp, 0, n_reads)
+        orc.bloom_insert(f, log2_bits, nh, seed, k, True, seq, off)
+    cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+    for mc in (1, 2):
+        km, cn, _ = orc.bloom_probe(f, log2_bits, nh, seed, k, True, cseq, coff, mc)
+        for windows in (1, 2):
+            hi = np.concatenate([outs[r][(windows, mc)][0] for r in range(world)])
+            lo = np.concatenate([outs[r][(windows, mc)][1] for r in range(world)])
+            cnt = np.concatenate([outs[r][(windows, mc)][2] for r in range(world)])
+            order = np.lexsort((lo, hi))
+            assert np.array_equal(hi[order], km["hi"]) and np.array_equal(lo[order], km["lo"]) and np.array_equal(cnt[order], cn)
+            assert all(len(outs[r][(windows, mc)][1]) > 0 for r in range(world))      # both ranks hold a share
+    assert int(cn.max()) >= 2
+
+
 def test_native_allreduce_world_one_through_the_abi():
     """dk_comm_init / dk_set_allreduce_or with one rank: the communicator is accepted, the all-reduce is the
     identity, a second communicator is refused.  (World sizes above one need one GPU per rank -- RCCL refuses two

@@ -10,6 +10,7 @@ import os
 import sys
 
 SHORT = {"scan_part_kernel": "scan_part", "repart_kernel": "repart", "seg_probe_kernel": "seg_probe",
+         "seg_probe_walk_kernel": "seg_probe", "seg_insert_walk_kernel": "seg_insert", "kmers_tile_kernel": "kmers",
          "seg_count_kernel": "seg_count", "seg_insert_kernel": "seg_insert", "seg_exact_probe_kernel": "seg_exact_probe",
          "seg_exact_insert_kernel": "seg_exact_insert", "probe_direct_kernel": "probe_direct",
          "insert_direct_kernel": "insert_direct", "count_insert_kernel": "count_insert", "count_emit_kernel": "count_emit"}
@@ -17,9 +18,37 @@ SHORT = {"scan_part_kernel": "scan_part", "repart_kernel": "repart", "seg_probe_
 
 def short_name(kernel):
     for key, val in SHORT.items():
-        if "dk::" + key in kernel:
+        if "dk::" + key + "<" in kernel or "dk::" + key + "(" in kernel:
             return val
     return None
+
+
+LAST = 7      # the timed steps (and their warm-up) are the last launches of every kernel: bench.py --steps 5 --warmup 2
+
+
+def trace_summary(src, dst):
+    """per engine kernel: average duration of its last LAST launches (the child steps; the parent build, which runs the
+    partition kernels on other shapes, comes first) and of all launches, from the kernel trace itself"""
+    path = find(os.path.join(src, "stats"), "*kernel_trace.csv")
+    by = {}
+    for r in csv.DictReader(open(path)):
+        name = short_name(r["Kernel_Name"])
+        if name is None:
+            continue
+        by.setdefault(name, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]),
+                                        r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", ""))))
+    rows = []
+    for name, ls in sorted(by.items()):
+        ls.sort()
+        last = ls[-LAST:]
+        rows.append({"Kernel": name, "Calls": len(ls), "AverageNs_all": round(sum(x[1] for x in ls) / len(ls)),
+                     "Last_launches": len(last), "AverageNs_last": round(sum(x[1] for x in last) / len(last)),
+                     "Grid_Size_last": last[-1][2], "Workgroup_Size_last": last[-1][3]})
+    with open(os.path.join(dst, "kernel_trace_summary.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows)
+    return rows
 
 
 def find(root, pattern):
@@ -49,6 +78,7 @@ def main():
     line = bench_line(os.path.join(src, "bench_under_stats.log"))
     if line:
         json.dump(line, open(os.path.join(dst, "bench_line_under_profiler.json"), "w"))
+    trows = trace_summary(src, dst)
     # 2. PMC passes
     per = {}
     for tag, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -69,11 +99,11 @@ def main():
     cfg = (line or {}).get("config", {})
     traffic = {"note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, tools/profile_round.sh). FETCH_SIZE "
                        "and WRITE_SIZE are in KiB; FETCH_SIZE is doubled for wide coalesced streaming reads on gfx950 "
-                       "(MI355X_MICROARCH.md, HBM section). The child-pass kernels are averaged over the launches of the "
-                       "largest grid size seen (the parent inserts launch the partition kernels too, with the same shapes).",
-               "reads": cfg.get("reads_per_gpu"), "log2_bits": cfg.get("filter_log2_bits"), "kernels": {}}
+                       "(MI355X_MICROARCH.md, HBM section). Every kernel is averaged over its last %d launches = the child "
+                       "steps (the parent inserts, which launch the partition kernels on other shapes, come first)." % LAST,
+               "workload": cfg.get("name"), "reads": cfg.get("reads_per_sample"), "log2_bits": cfg.get("filter_log2_bits"), "kernels": {}}
     for name, c in per.items():
-        f, wv = c.get("FETCH_SIZE", []), c.get("WRITE_SIZE", [])
+        f, wv = c.get("FETCH_SIZE", [])[-LAST:], c.get("WRITE_SIZE", [])[-LAST:]
         if not f or not wv:
             continue
         fm, wm = sum(f) / len(f), sum(wv) / len(wv)
@@ -82,8 +112,8 @@ def main():
                                     "fetch_size_raw_kib": fm, "write_size_raw_kib": wm, "launches_seen": min(len(f), len(wv))}
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in traffic["kernels"].items()}))
-    for r in keep[:8]:
-        print(r["Name"][:60], r["Calls"], r["AverageNs"])
+    for r in trows:
+        print(r)
 
 
 if __name__ == "__main__":
