@@ -194,7 +194,7 @@ def main():
     import torch.distributed as dist
 
     import denovo_kmer_amd as dk
-    from denovo_kmer_amd.dist import comm_init_from_torch, filter_digest, local_reduce_fn, or_allreduce_
+    from denovo_kmer_amd.dist import accum_exchange_finish, comm_init_from_torch, merge_counts_device, filter_digest, local_reduce_fn, or_allreduce_
 
     wl = dict(WORKLOADS[args.workload])
     for key, val in (("k", args.k), ("reads", args.reads), ("batch", args.batch), ("parent_batch", args.parent_batch),
@@ -322,9 +322,11 @@ def main():
 
     # ---- child membership pass: warmup + K timed steps -----------------------------------------------
     stage_sum, total_dev_ms, step_stats = {}, 0.0, None
-    finish_stats, windows_timed = None, 0
+    finish_stats, windows_timed, n_flushes, step_ms = None, 0, 0, []
     if wgs:
-        R = wl["windows"]
+        # hash-window passes: what one rank accumulates per pass must fit beside the filter (and, for N > 1, beside the
+        # pieces it receives from the other ranks): 2 passes up to two ranks, 1 from four ranks on
+        R = args.windows or (wl["windows"] if world <= 2 else 1)
         # expected absent occurrences per pass: windows with >= 1 error base, plus filter false positives on the safe side
         p_err = 1.0 - (1.0 - wl["err"]) ** k
         cap = int(1.12 * p_err * reads_rank * (L - k + 1) / R)
@@ -335,26 +337,47 @@ def main():
             lo, n = batch_range(b)
             resident.append(dk.ReadBatch.synth(eng, gcfg, 2, lo, n))
         progress("child: %d resident batches, accumulator of %.1f GB" % (n_res, acc.device_bytes() / 1e9))
-        for i in range(args.warmup):
-            acc.add(resident[i % n_res])
+        finish_stages, n_flushes = {}, 0
+
+        def flush():
+            # counting of what was accumulated is part of the job; N > 1: the ranks first swap unit ranges, so that counts
+            # and min_count are exact across the read shards (each rank ends with its share of the hash space)
+            res = accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
+            st, t = res.stats, eng.timings()
+            res.close()
+            return st, t
+
+        # The steps walk the rank's child batches like a real pass does: when the pass is complete (every resident batch
+        # added once: only with few batches per rank, i.e. many GPUs) it is counted and the accumulator starts over
+        for j in range(args.warmup):
+            acc.add(resident[j % n_res])
+            if (j + 1) % n_res == 0:
+                flush()
+                acc.reset(0)
+        flush()                              # warm-up of the counting stage too (its table comes from the workspace pool)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            st = acc.add(resident[(args.warmup + i) % n_res])
+            j = args.warmup + i
+            st = acc.add(resident[j % n_res])
             step_stats = st
             windows_timed += st["n_windows"]
             t = eng.timings()
             total_dev_ms += t["total_ms"]
+            step_ms.append([round(ms, 2) for _, ms in t["stages"]])
             for name, ms in t["stages"]:
                 stage_sum[name] = stage_sum.get(name, 0.0) + ms
-        res = acc.finish(min_count=wl["min_count"])          # counting of what the steps accumulated: part of the job
-        finish_stats = res.stats
-        t = eng.timings()
-        finish_stages = {name: ms for name, ms in t["stages"]}
-        total_dev_ms += t["total_ms"]
-        res.close()
+            if (j + 1) % n_res == 0 or i == args.steps - 1:
+                fst, t = flush()
+                n_flushes += 1
+                finish_stats = fst if finish_stats is None else {key: finish_stats[key] + fst[key] for key in fst}
+                total_dev_ms += t["total_ms"]
+                for name, ms in t["stages"]:
+                    finish_stages[name] = finish_stages.get(name, 0.0) + ms
+                if i != args.steps - 1:
+                    acc.reset(0)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -418,7 +441,7 @@ def main():
                 if w == 0:
                     child_windows += st["n_windows"]
                 cb.close()
-            res = acc.finish(min_count=wl["min_count"])
+            res = accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
             progress("end to end: pass %d of %d counted" % (w + 1, R))
             n_child_only += len(res)
             n_absent_all += res.stats["n_absent"]
@@ -439,11 +462,38 @@ def main():
                "child_gkmers_s": child_windows / (child_seconds - gen_s) / 1e9,
                "hash_windows": R, "batches_per_pass": n_batches, "min_count": wl["min_count"],
                "absent_occurrences": n_absent_all, "child_only_kmers": n_child_only,
+               "trio_seconds": parent_seconds + allreduce_ms * 1e-3 + child_seconds,
+               "trio_gkmers_s": (parent_windows + child_windows) / (parent_seconds + allreduce_ms * 1e-3 + child_seconds) / 1e9,
                "parent_reads": 2 * reads_total, "parent_windows": parent_windows, "parent_seconds": parent_seconds,
                "note": "read generation (synthetic, on the GPU) is inside child_seconds / parent_seconds and subtracted for child_gkmers_s; "
-                       + ("per-rank child-only tables are not merged across ranks in this run" if world > 1 else "one GPU")}
+                       + ("the ranks swap accumulator unit ranges before counting (dist.accum_exchange_finish): counts are exact across "
+                          "the read shards, every rank keeps its share of the hash space" if world > 1 else "one GPU")}
     if wgs:
         acc.close()
+    elif world > 1:
+        # chr20 / ont over several GPUs, end to end: one more child pass per rank + the cross-rank sum of the per-rank
+        # tables on the device (every rank ends with the whole child-only table)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = counter.child_only(child, kset)
+        merged = merge_counts_device(eng, r, min_count=wl["min_count"], stage_through_cpu=on_host)
+        torch.cuda.synchronize()
+        dist.barrier()
+        child_seconds = time.perf_counter() - t0
+        tt = torch.tensor([child_seconds, parent_seconds], dtype=torch.float64, device=sdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        child_seconds, parent_seconds = (float(x) for x in tt)
+        cc = torch.tensor([r.stats["n_windows"], parent_windows], dtype=torch.float64, device=sdev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        child_windows, parent_windows = (float(x) for x in cc)
+        e2e = {"child_windows": child_windows, "child_seconds_probe_plus_cross_rank_merge": child_seconds,
+               "child_only_kmers_after_merge": len(merged), "parent_windows": parent_windows, "parent_seconds": parent_seconds,
+               "trio_seconds": parent_seconds + allreduce_ms * 1e-3 + child_seconds,
+               "trio_gkmers_s": (parent_windows + child_windows) / (parent_seconds + allreduce_ms * 1e-3 + child_seconds) / 1e9,
+               "note": "parent insert (incl. synthetic read generation) + set all-reduce + child pass + merge_counts_device over all ranks"}
+        merged.close()
+        r.close()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -476,10 +526,11 @@ def main():
                        "reads_per_step": batch, "read_len": L, "filter_log2_bits": args.log2_bits, "n_hashes": args.n_hashes,
                        "mode": args.mode, "set_kind": args.set_kind, "hash_windows": R, "engine_options": args.opt,
                        "windows_counted_per_step": "n_windows / hash_windows",
+                       "counting_passes_inside_timed_region": n_flushes if wgs else None,
                        "parallelism": "reads sharded x%d, %s-all-reduce of parent set" % (world, "OR" if args.set_kind == "bloom" else "union")},
             "roofline": rl,
             "stages_ms": stages,
-            "device_ms_per_step": total_dev_ms / args.steps,
+            "device_ms_per_step": total_dev_ms / args.steps, "stage_ms_of_each_step": step_ms,
             "pass_stats": step_stats,
             "parent_build": {"insert_gkmers_s": insert_windows / (insert_ms * 1e-3) / 1e9 if insert_ms else None,
                              "insert_ms_per_batch": insert_ms, "insert_stages_ms": insert_stages, "batches": 2 * n_pbatches,

@@ -110,7 +110,7 @@ def accum_exchange_finish(acc, min_count=1, group=None, stage_through_cpu=False)
     space with counts summed over ALL ranks' reads, min_count applied to the sums; the ranks' tables are disjoint and
     their union is the answer, so nothing is ever gathered on one GPU.  The (rare) overflow lists are all-gathered.
     stage_through_cpu: move the payloads through host memory (gloo rehearsal on one GPU)."""
-    world = dist.get_world_size(group)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return acc.finish(min_count=min_count)
     rank = dist.get_rank(group)
