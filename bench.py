@@ -311,6 +311,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         allreduce_ms = (time.perf_counter() - t0) * 1e3
+        torch.cuda.empty_cache()             # the torch path stages a second copy of the set: hand it back to the device
     # every rank must now hold the same filter: compare a digest of the words (XOR/sum of mixed words) across ranks
     popc = kset.popcount()
     digest = filter_digest(filt)
@@ -325,8 +326,8 @@ def main():
     finish_stats, windows_timed, n_flushes, step_ms = None, 0, 0, []
     if wgs:
         # hash-window passes: what one rank accumulates per pass must fit beside the filter (and, for N > 1, beside the
-        # pieces it receives from the other ranks): 2 passes up to two ranks, 1 from four ranks on
-        R = args.windows or (wl["windows"] if world <= 2 else 1)
+        # pieces it receives from the other ranks): 2 passes up to four ranks, 1 from eight ranks on
+        R = args.windows or (wl["windows"] if world <= 4 else 1)
         # expected absent occurrences per pass: windows with >= 1 error base, plus filter false positives on the safe side
         p_err = 1.0 - (1.0 - wl["err"]) ** k
         cap = int(1.12 * p_err * reads_rank * (L - k + 1) / R)

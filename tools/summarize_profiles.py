@@ -78,6 +78,9 @@ def main():
     line = bench_line(os.path.join(src, "bench_under_stats.log"))
     if line:
         json.dump(line, open(os.path.join(dst, "bench_line_under_profiler.json"), "w"))
+    lines = [l for l in open(os.path.join(src, "bench_under_stats.log")) if l.startswith("{")]
+    if len(lines) > 1:                       # drivers that print one line per configuration (tools/kmers_bench.py)
+        open(os.path.join(dst, "bench_lines_under_profiler.jsonl"), "w").writelines(lines)
     trows = trace_summary(src, dst)
     # 2. PMC passes
     per = {}
