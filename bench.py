@@ -186,7 +186,7 @@ def main():
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
-                    help="engine option for A/B runs (dk_engine_set_option), e.g. --opt sweep_variant=1")
+                    help="engine option for A/B runs (dk_engine_set_option), e.g. --opt repart_plain=1")
     args = ap.parse_args()
 
     import numpy as np  # noqa: F401

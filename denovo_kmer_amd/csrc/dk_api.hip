@@ -555,7 +555,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"count_seg", &dk_options::count_seg, 0, 1 << 30},
         {"cnt_mid", &dk_options::cnt_mid, 0, 1 << 30},
         {"sub_split", &dk_options::sub_split, 0, 9},
-        {"sweep_variant", &dk_options::sweep_variant, 0, 2},
+        {"repart_plain", &dk_options::repart_plain, 0, 1},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"merge_idx64", &dk_options::merge_idx64, 0, 1},
     };

@@ -24,7 +24,7 @@ struct dk_options {
     int b1_up = 0;                // shift the level-1 / level-2 bit split
     int count_seg = 0;            // KmerCounter: records per counting segment (default 5000)
     int cnt_mid = 0;              // seg_count: threshold of the 512-thread geometry (default 3600)
-    int sweep_variant = 0;        // set kernels: 1 = one workgroup per segment, 2 = persistent walk, 0 = by segment count
+    int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
     int sub_split = 0;            // sub-segment split of the set kernels: 0 = automatic, 1..3 = force, 9 = never
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes
     int merge_idx64 = 0;          // dk_result_merge: 64-bit candidate indices whatever the size

@@ -35,6 +35,11 @@ constexpr int MAX_SEG_BITS = 23;                       // two levels up to 18 bi
 constexpr int CURSOR_STRIDE = 32;                      // level-1 cursors on separate 128-B lines
 
 constexpr int SEG_THREADS = 1024;
+// The set kernels keep one 64-KiB segment in LDS and run two workgroups of 1024 threads per CU, i.e. 8 waves per SIMD:
+// that needs at most 64 VGPRs AND at most 80 SGPRs per wave -- the CU admits floor(800 / (ceil(sgpr / 16) * 16 + 16))
+// waves per SIMD (MI355X_MICROARCH.md, Residency), and a kernel at 87 SGPRs silently ran one workgroup per CU
+// (seg_probe 9.6 -> 13.2 ms at 2^39 bits).  `make resources` prints what the compiler settled on.
+#define DK_SEG_KERNEL __global__ void __launch_bounds__(SEG_THREADS, 8) __attribute__((amdgpu_num_sgpr(72)))
 constexpr uint32_t NO_RANK = 0xFFFFFFFFu;
 
 constexpr int MAX_R = 8;                               // pieces per counting unit: adjacent segments counted together, or the ranks of a multi-GPU run
@@ -554,14 +559,21 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES, class R>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
-              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr)
+              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0)
 {
     constexpr int TILE = THREADS * PER_THREAD;
     __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
     // one-dimensional grid (the number of bins can exceed the 65535 of grid.y): bin-major, then piece, then tile
     const uint32_t per_bin = G * tiles_per_piece;
-    const uint32_t b = blockIdx.x / per_bin, bx = blockIdx.x % per_bin;
+    uint32_t b = blockIdx.x / per_bin, bx = blockIdx.x % per_bin;
+    if (xcd_affine) {
+        // eight bins at a time, one per XCD (consecutive blocks are dealt round-robin over the XCDs): all tiles of a bin
+        // then append to its 2^b2 frontiers through ONE L2, which assembles whole lines (speed only)
+        const uint32_t slot = blockIdx.x >> 3;
+        b = 8 * (slot / per_bin) + (blockIdx.x & 7);
+        bx = slot % per_bin;
+    }
     const uint32_t w = bx / tiles_per_piece, t0 = (bx % tiles_per_piece) * TILE;
     const uint64_t piece = (uint64_t)b * G + w;
     uint32_t n = cnt1[piece];
@@ -682,10 +694,12 @@ struct SegPieces {
     uint64_t piece_stride;         // records between two pieces of the segment
     const R *extra;                // extra records of the segment (or nullptr)
     uint32_t n_extra;
+    bool single;                   // one piece (the usual case): no search for the piece of a record
     __device__ __forceinline__ uint32_t total() const { return start[MAX_R] + n_extra; }
     __device__ __forceinline__ R at(uint32_t i) const
     {
         if (i >= start[MAX_R]) return extra[i - start[MAX_R]];
+        if (single) return base[i];
         uint32_t r = 0, st = 0;
 #pragma unroll
         for (int q = 1; q < MAX_R; q++)
@@ -728,6 +742,7 @@ __device__ __forceinline__ SegPieces<R> seg_pieces(const PieceList<R> &pl, uint6
         acc += sc.c[q] < pl.piece_cap ? sc.c[q] : pl.piece_cap;
     }
     sp.start[MAX_R] = acc;
+    sp.single = pl.n_pieces == 1;
     sp.extra = pl.extra ? pl.extra + sc.o0 : nullptr;
     sp.n_extra = sc.o1 - sc.o0;
     return sp;
@@ -748,9 +763,10 @@ __device__ __forceinline__ void load_segment(uint32_t *seg, const unsigned long 
 
 // Which 64-KiB segment a workgroup of the set kernels takes: simply its block index.  (With a sub-segment split,
 // placing the 2^sbits workgroups that share a region on one XCD -- block indices 8 apart, so that the region's second
-// reading hits that XCD's L2 -- measured slower: seg_probe 13.2 ms against 9.8 ms at 2^39 bits, two hash windows,
-// 24 M reads; consecutive blocks reading consecutive segments spread the sweep evenly over XCDs and channels.)
-__device__ __forceinline__ uint64_t segment_of_block(int, uint64_t) { return blockIdx.x; }
+// reading could hit that XCD's L2 -- changed nothing: seg_probe 9.32 vs 9.28 ms at 2^39 bits, two hash windows, 24 M
+// reads.  Keeping the region's records in registers while one workgroup stages both segments in turn does not fit the
+// 64 VGPRs that two workgroups per CU allow.)
+__device__ __forceinline__ uint64_t segment_of_block() { return blockIdx.x; }
 
 // The three dependent fetches of a segment workgroup -- piece sizes, the 64-KiB segment, the first records -- are
 // issued back to back: the segment travels to registers while the sizes arrive, the first records are requested as
@@ -776,11 +792,11 @@ __device__ __forceinline__ void stage_segment(uint32_t *seg, const SegRegs &r)
 }
 
 template <class R>
-__global__ void __launch_bounds__(SEG_THREADS)
+DK_SEG_KERNEL
 seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
-    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const uint64_t seg_id = segment_of_block();
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
     const SegRegs sr = fetch_segment(filter, seg_id);
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
@@ -905,13 +921,13 @@ struct MissSink {
 // NH > 0: the number of hash bits is a compile-time constant (the four LDS reads of a record are then
 // issued back to back instead of one by one behind the short-circuit test); NH == 0: n_hashes at run time
 template <class R, int NH, bool ACC>
-__global__ void __launch_bounds__(SEG_THREADS)
+DK_SEG_KERNEL
 seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
                  uint64_t seg_base, MissOut<R> mo, Counters *ctr)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
     __shared__ uint32_t sfill[ACC ? SUB_TALLY + 1 : 1];
-    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const uint64_t seg_id = segment_of_block();
     const bool no_set = filter == nullptr;    // accumulating KmerCounter: every record counts as absent
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
     SegRegs sr;
@@ -972,155 +988,16 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     sink.finish(ctr, my_absent);
 }
 
-// ---- persistent sweep: 2 workgroups per CU walk the segments ------------------------------------------------------
-// With 2^19 - 2^20 segments of a few thousand records each (whole-genome sets) a workgroup per segment spends most
-// of its life waiting for its own three round trips to HBM and being launched.  Here a workgroup walks segments
-// blockIdx.x, + gridDim.x, ...: while it tests the records of one segment in LDS, the next segment and its piece
-// sizes are already travelling to its registers; barriers order LDS traffic only (lds_barrier), so they do not
-// wait for those loads.  Same results as the per-segment kernels (tests run both).
-template <class R, int NH, bool ACC>
-__global__ void __launch_bounds__(SEG_THREADS)
-seg_probe_walk_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
-                      uint64_t seg_base, MissOut<R> mo, Counters *ctr, uint64_t n_seg)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
-    __shared__ uint32_t sfill[ACC ? SUB_TALLY + 1 : 1];
-    uint64_t seg_id = blockIdx.x;
-    if (seg_id >= n_seg) return;
-    SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
-    SegRegs sr = fetch_segment(filter, seg_base + seg_id);
-    constexpr int UNROLL = 8;
-    for (;;) {
-        const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
-        const uint32_t n = sp.total();
-        R rec[UNROLL];
-        bool have[UNROLL];
-        auto fetch = [&](uint32_t i0) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
-                have[u] = i < n;
-                rec[u] = sp.at(have[u] ? i : 0);
-            }
-        };
-        fetch(0);
-        MissSink<R, ACC> sink(sfill, mo, seg_id);
-        stage_segment(seg, sr);
-        lds_barrier();
-        const uint64_t next = seg_id + gridDim.x;
-        const bool has_next = next < n_seg;
-        if (has_next) {                       // in flight while this segment is probed
-            sc = seg_counts(pl, next >> pl.sbits);
-            sr = fetch_segment(filter, seg_base + next);
-        }
-        uint32_t my_absent = 0;
-        for (uint32_t i0 = 0;;) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const uint64_t hu = rec[u].h;
-                const uint32_t blk = (uint32_t)(hu >> blk_shift) & (SEG_BLOCKS - 1);
-                const uint32_t a = (uint32_t)(hu & 511), d = (uint32_t)((hu >> 9) & 511) | 1u;
-                bool all = true;
-                if constexpr (NH > 0) {
-                    uint32_t acc = 1u;
-#pragma unroll
-                    for (int j = 0; j < NH; j++) {
-                        const uint32_t bit = (a + (uint32_t)j * d) & 511;
-                        acc &= seg[blk * 16 + (bit >> 5)] >> (bit & 31);
-                    }
-                    all = acc & 1u;
-                } else {
-                    for (int j = 0; j < n_hashes; j++) {
-                        const uint32_t bit = (a + (uint32_t)j * d) & 511;
-                        all = all && ((seg[blk * 16 + (bit >> 5)] >> (bit & 31)) & 1u);
-                    }
-                }
-                const bool absent = have[u] && !all && pl.mine(seg_id, hu);
-                my_absent += absent;
-                sink.put(absent, rec[u]);
-            }
-            i0 += UNROLL * SEG_THREADS;
-            if (i0 >= n) break;
-            fetch(i0);
-        }
-        lds_barrier();
-        sink.finish(ctr, my_absent);
-        lds_barrier();                        // seg[] and sfill[] are free for the next segment
-        if (!has_next) break;
-        seg_id = next;
-    }
-}
-
-template <class R>
-__global__ void __launch_bounds__(SEG_THREADS)
-seg_insert_walk_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift, uint64_t n_seg)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
-    uint64_t seg_id = blockIdx.x;
-    if (seg_id >= n_seg) return;
-    SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
-    SegRegs sr = fetch_segment(filter, seg_id);
-    constexpr int UNROLL = 8;
-    for (;;) {
-        const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
-        const uint32_t n = sp.total();
-        uint64_t h[UNROLL];
-        bool have[UNROLL];
-        auto fetch = [&](uint32_t i0) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
-                have[u] = i < n;
-                h[u] = sp.at(have[u] ? i : 0).h;
-            }
-        };
-        fetch(0);
-        stage_segment(seg, sr);
-        lds_barrier();
-        const uint64_t next = seg_id + gridDim.x;
-        const bool has_next = next < n_seg;
-        if (has_next) {
-            sc = seg_counts(pl, next >> pl.sbits);
-            sr = fetch_segment(filter, next);
-        }
-        for (uint32_t i0 = 0;;) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; u++) {
-                if (!have[u] || !pl.mine(seg_id, h[u])) continue;
-                const uint32_t blk = (uint32_t)(h[u] >> blk_shift) & (SEG_BLOCKS - 1);
-                const uint32_t a = (uint32_t)(h[u] & 511), d = (uint32_t)((h[u] >> 9) & 511) | 1u;
-                for (int j = 0; j < n_hashes; j++) {
-                    const uint32_t bit = (a + (uint32_t)j * d) & 511;
-                    atomicOr(&seg[blk * 16 + (bit >> 5)], 1u << (bit & 31));
-                }
-            }
-            i0 += UNROLL * SEG_THREADS;
-            if (i0 >= n) break;
-            fetch(i0);
-        }
-        lds_barrier();
-        if (n) {                              // nothing added: the segment in HBM is already right
-            uint4 *dst = (uint4 *)filter + seg_id * (SEG_BYTES / 16);
-            const uint4 *s4 = (const uint4 *)seg;
-#pragma unroll
-            for (int q = 0; q < SEG_VEC; q++) dst[q * SEG_THREADS + (int)threadIdx.x] = s4[q * SEG_THREADS + (int)threadIdx.x];
-        }
-        lds_barrier();                        // every thread has read its part of seg[] back
-        if (!has_next) break;
-        seg_id = next;
-    }
-}
-
 // ---- exact set: the segment is an open-addressing table (dk_device.h) -----------------------------
 // Same shape as seg_insert / seg_probe: segment -> LDS, one LDS operation chain per record, segment back.
 template <class R>
-__global__ void __launch_bounds__(SEG_THREADS)
+DK_SEG_KERNEL
 seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Counters *ctr)
 {
     constexpr bool WIDE = sizeof(R) == 16;
     static_assert(SEG_BYTES == EXACT_SEG_WORDS * 8, "exact segments are the filter segments");
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
-    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const uint64_t seg_id = segment_of_block();
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
     const SegRegs sr = fetch_segment(table, seg_id);
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
@@ -1164,14 +1041,14 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
 // against 5.1 ms for this form at 2^17 segments: the hardware's workgroup scheduler overlaps the
 // segments' load / probe phases better than two resident persistent workgroups per CU do.)
 template <class R, bool ACC>
-__global__ void __launch_bounds__(SEG_THREADS)
+DK_SEG_KERNEL
 seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T, uint64_t seg_base,
                        MissOut<R> mo, Counters *ctr)
 {
     constexpr bool WIDE = sizeof(R) == 16;
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
     __shared__ uint32_t sfill[ACC ? SUB_TALLY + 1 : 1];
-    const uint64_t seg_id = segment_of_block(pl.sbits, gridDim.x);
+    const uint64_t seg_id = segment_of_block();
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
     const SegRegs sr = fetch_segment(table, seg_base + seg_id);
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
@@ -1881,14 +1758,15 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<repart_grid(p.G * tpp, p.p1), TH, 0, e->stream>>>(                   \
             B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
-            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr);                                                  \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, !e->opt.repart_plain && p.p1 % 8 == 0);              \
     } while (0)
     // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
 #define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \
     do {                                                                                                  \
         const uint32_t tpp = (p.capA + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<repart_grid(tpp, 1u << (p.b1 + p.b2)), TH, 0, e->stream>>>(          \
-            B.b, B.cursorA, 1u, p.capA, tpp, wbits + p.b1 + p.b2, p.b3, p.cap2, B.a, B.cursor2, ovf, e->d_ctr); \
+            B.b, B.cursorA, 1u, p.capA, tpp, wbits + p.b1 + p.b2, p.b3, p.cap2, B.a, B.cursor2, ovf, e->d_ctr,  \
+            !e->opt.repart_plain && ((1u << (p.b1 + p.b2)) % 8 == 0));                                        \
     } while (0)
     if constexpr (WIDE) {
         if (wbits) DK_SCAN_LAUNCH(512, 8, 4, true);
@@ -1956,15 +1834,10 @@ inline dk_status sync_counters(dk_engine *e, const char *what)
     return DK_OK;
 }
 
-// Option "sweep_variant": 1 = one workgroup per segment, 2 = persistent walk, 0 = automatic: the walk for seg_insert
-// from 2^19 segments on (34.9 -> 32.7 ms per 48 M reads at 2^39 bits), never for the probe (9.8 -> 12.8 ms there: the
-// hardware's workgroup scheduler overlaps the short probe phases better than two resident walkers per CU do)
-inline bool sweep_walks(const dk_engine *e, uint64_t n_seg, bool insert)
-{
-    if (e->opt.sweep_variant) return e->opt.sweep_variant == 2;
-    return insert && n_seg >= (1ULL << 19);
-}
-
+// (A persistent walk of the set kernels -- two workgroups per CU stepping through the segments with the next segment
+// in flight to registers while the current one is probed -- measured no better for seg_insert (33.8-35.2 vs 34.1 ms per
+// 48 M reads at 2^39 bits) and worse for seg_probe (16 vs 9.5 ms: the prefetch registers spill at the 64 VGPRs that two
+// workgroups per CU allow); one workgroup per segment it is.)
 // Returns DK_ERR_OVERFLOW when even the overflow list overflowed: the caller then runs the direct
 // family on the whole batch, which is exact (OR is idempotent, records already inserted do no harm).
 template <bool WIDE>
@@ -1983,9 +1856,6 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
         const unsigned n_seg = (unsigned)(p.n_seg << p.sbits);
         if (s->exact)
             seg_exact_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, T_full, e->d_ctr);
-        else if (sweep_walks(e, n_seg, true))
-            seg_insert_walk_kernel<R><<<std::min<unsigned>(n_seg, (unsigned)e->n_cu * 2), SEG_THREADS, 0, e->stream>>>(
-                s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS, n_seg);
         else
             seg_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(
                 s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS);
@@ -2017,16 +1887,6 @@ inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &
                                    uint64_t seg_base, const MissOut<R> &mo)
 {
     const int blk_shift = 64 - T_full - SEG_LOG2_BLOCKS;
-    if (!(s && s->exact) && sweep_walks(e, n_seg, false)) {
-        // persistent walk (Bloom sets with many small segments)
-        const unsigned grid = (unsigned)std::min<uint64_t>(n_seg, (uint64_t)e->n_cu * 2);
-        if (s && e->cfg.n_hashes == 4)
-            seg_probe_walk_kernel<R, 4, ACC><<<grid, SEG_THREADS, 0, e->stream>>>(s->d_words, list, 4, blk_shift, seg_base, mo, e->d_ctr, n_seg);
-        else
-            seg_probe_walk_kernel<R, 0, ACC><<<grid, SEG_THREADS, 0, e->stream>>>(
-                s ? s->d_words : nullptr, list, s ? (int)e->cfg.n_hashes : 0, blk_shift, seg_base, mo, e->d_ctr, n_seg);
-        return hipGetLastError();
-    }
     if (s && s->exact)
         seg_exact_probe_kernel<R, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, T_full, seg_base, mo, e->d_ctr);
     else if (s && e->cfg.n_hashes == 4)

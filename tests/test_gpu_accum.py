@@ -33,8 +33,8 @@ def ragged_batches(reads, cuts):
 
 @pytest.mark.parametrize("mode", ["direct", "bucketed"])
 @pytest.mark.parametrize("k,set_kind,log2_bits", [(31, "bloom", 24), (45, "bloom", 24), (31, "exact", 26), (51, "exact", 26)])
-@pytest.mark.parametrize("window_count,sub_split,sweep", [(1, 0, 0), (4, 0, 2), (1, 2, 0), (2, 1, 2), (2, 1, 1)])
-def test_accumulated_batches_equal_the_whole_sample(mode, k, set_kind, log2_bits, window_count, sub_split, sweep):
+@pytest.mark.parametrize("window_count,sub_split", [(1, 0), (4, 0), (1, 2), (2, 1)])
+def test_accumulated_batches_equal_the_whole_sample(mode, k, set_kind, log2_bits, window_count, sub_split):
     d = dk()
     rng = np.random.default_rng(1234 + k)
     parents, child = related_trio(rng, genome_len=20000, n_reads=700, read_len=130)
@@ -47,7 +47,6 @@ def test_accumulated_batches_equal_the_whole_sample(mode, k, set_kind, log2_bits
         orc.bloom_insert(f, log2_bits, 4, 5, k, True, pseq, poff)
     with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=5, mode=mode, set_kind=set_kind) as eng:
         eng.set_option("sub_split", sub_split)          # segment kernels share partition regions (what 2^38-bit sets do)
-        eng.set_option("sweep_variant", sweep)          # 2: persistent walk over the segments (what 2^19 segments and more do)
         ks = d.KmerSet(eng)
         ks.insert_sequences(parents)
         acc = d.ChildAccumulator(eng, ks, capacity_records=200_000, window_count=window_count)

@@ -658,22 +658,10 @@ def test_sub_segment_split_of_the_insert_kernels(sub_split):
         assert_result_equals(res, km, cn)
 
 
-@pytest.mark.parametrize("options", [{"sweep_variant": 2}, {"sweep_variant": 2, "sub_split": 1}, {"sweep_variant": 1}])
-def test_persistent_walk_of_the_set_kernels(options):
-    """sweep_variant 2 forces the persistent, software-pipelined seg_insert / seg_probe that sets of 2^19 segments and
-    more use by themselves (sweep_variant 1: one workgroup per segment everywhere)"""
-    _forced_geometry_trio(options, ["scan_part", "repart"])
-    d = dk()
-    rng = np.random.default_rng(5)
-    parents, child = related_trio(rng, genome_len=30000, n_reads=900, read_len=140)
-    f, ist, km, cn, pst = oracle_trio(parents, child, 31, 20, 3, 7)      # two segments, 1 workgroup each, many records
-    with d.Engine(k=31, filter_log2_bits=20, n_hashes=3, seed=7, mode="bucketed") as eng:
-        for name, value in options.items():
-            if name != "sub_split":
-                eng.set_option(name, value)
-        ks, _, res = gpu_trio(eng, parents, child)
-        assert np.array_equal(ks.to_host(), f)
-        assert_result_equals(res, km, cn)
+def test_repart_in_plain_block_order_agrees():
+    """repart deals its tiles one bin per XCD by default; repart_plain restores plain block order (A/B runs)"""
+    _forced_geometry_trio({"repart_plain": 1}, ["scan_part", "repart"])
+    _forced_geometry_trio({"repart_plain": 1, "force_l3": 1}, ["scan_part", "repart", "repart3"])
 
 
 def test_forced_scan_shape_with_fewer_threads_than_bins():
