@@ -554,6 +554,8 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"b1_up", &dk_options::b1_up, -4, 4},
         {"count_seg", &dk_options::count_seg, 0, 1 << 30},
         {"cnt_mid", &dk_options::cnt_mid, 0, 1 << 30},
+        {"cnt_big", &dk_options::cnt_big, 0, 1 << 30},
+        {"cnt_split_to", &dk_options::cnt_split_to, 0, 1 << 30},
         {"sub_split", &dk_options::sub_split, 0, 9},
         {"repart_plain", &dk_options::repart_plain, 0, 1},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},

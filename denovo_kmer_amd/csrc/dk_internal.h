@@ -24,6 +24,8 @@ struct dk_options {
     int b1_up = 0;                // shift the level-1 / level-2 bit split
     int count_seg = 0;            // KmerCounter: records per counting segment (default 5000)
     int cnt_mid = 0;              // seg_count: threshold of the 512-thread geometry (default 3600)
+    int cnt_big = 0;              // seg_count: threshold of the 1024-thread geometry (default 7000, k > 32: 3500)
+    int cnt_split_to = 0;         // absent-list split: records per unit aimed at (default 6000, k > 32: 3000)
     int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
     int sub_split = 0;            // sub-segment split of the set kernels: 0 = automatic, 1..3 = force, 9 = never
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes

@@ -1198,6 +1198,11 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             w = b >> 5;
             m = 1u << (b & 31);
         };
+        // k > 32: the bitmap position of a record costs an fmix64; with the records in registers (single) it is
+        // computed once and kept, like the verdict of pass 2 (fbits) that passes 3 and 4 would otherwise re-derive
+        constexpr bool KEEP_BITS = WIDE && CNT_RPT == 8;
+        uint32_t bidx[KEEP_BITS ? CNT_RPT : 1];
+        uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
         for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
         if (single) load_chunk(0);
         __syncthreads();
@@ -1209,6 +1214,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 if (!have(c, u)) continue;
                 uint32_t w, m;
                 bit_of(hv[u], w, m);
+                if constexpr (KEEP_BITS) bidx[u] = (w << 5) | (uint32_t)__builtin_ctz(m);
                 if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
             }
         }
@@ -1221,11 +1227,17 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             for (int u = 0; u < CNT_RPT; u++) {
                 if (!have(c, u)) continue;
                 uint32_t w, m;
-                bit_of(hv[u], w, m);
-                if (bm_b[w] & m) my_flagged++; else my_unique++;
+                if (KEEP_BITS && single) { w = bidx[u] >> 5; m = 1u << (bidx[u] & 31); }
+                else bit_of(hv[u], w, m);
+                const bool fl = (bm_b[w] & m) != 0;
+                if (fl) my_flagged++; else my_unique++;
+                if constexpr (KEEP_BITS) fbits |= (fl ? 1u : 0u) << u;
             }
         }
-        auto flagged = [&](int, const R &rec) -> bool {
+        auto flagged = [&](int u, const R &rec) -> bool {
+            if constexpr (KEEP_BITS) {
+                if (single) return (fbits >> u) & 1u;
+            }
             uint32_t w, m;
             bit_of(rec, w, m);
             return (bm_b[w] & m) != 0;
@@ -1911,7 +1923,7 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
     if (!n_absent) return DK_OK;
     const uint64_t per_seg = n_absent / n_units;
     auto launch = [&](uint64_t region_cap) -> hipError_t {
-        if (per_seg >= (WIDE ? 3500u : 7000u)) {
+        if (per_seg >= (e->opt.cnt_big > 0 ? (uint64_t)e->opt.cnt_big : (WIDE ? 3500u : 7000u))) {
             // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
             const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 2);
             seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
@@ -2062,7 +2074,9 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     // then split once more by the next hash bits -- the level-3 use of repart, over the absent lists instead of
     // coarse regions -- into units of ~5 K records; the space of the probed records is free for the result.
     // (a seg_count workgroup holds 16 K records of 8 bytes, 8 K of 16)
-    const uint64_t split_above = WIDE ? 7000 : 14000, split_to = WIDE ? 3000 : 6000;
+    // (k > 32: units of ~3.3 K records for the 512-thread count kernel, whose registers hold 4 K: 26.6 ms against 33.6 ms with
+    // units of 1.6 K and 45 ms with the 1024-thread kernel on the configs[4] batch)
+    const uint64_t split_above = WIDE ? 7000 : 14000, split_to = e->opt.cnt_split_to > 0 ? (uint64_t)e->opt.cnt_split_to : (WIDE ? 3400 : 6000);
     if (st == DK_OK && s && unit_pieces == 1 && !list.extra && n_absent / p.n_seg > split_above) {
         int bs = 1;
         while (bs < MAX_BIN_BITS && (n_absent >> (p.T + bs)) > split_to) bs++;
