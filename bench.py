@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 XGMI_LINK_GBS = 153.0          # per link, 7 links per GPU
 
 WORKLOADS = {
-    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=24_000_000, parent_batch=48_000_000, log2_bits=39, err=5e-3,
+    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=32_000_000, parent_batch=64_000_000, log2_bits=39, err=5e-3,
                 min_count=2, windows=2, cfg="configs[2]"),
     "chr20": dict(k=31, read_len=150, reads=12_800_000, batch=12_800_000, parent_batch=12_800_000, log2_bits=34, err=5e-3,
                   min_count=1, windows=1, cfg="configs[1]"),
@@ -238,8 +238,16 @@ def main():
     for ov in args.opt:
         name, _, val = ov.partition("=")
         eng.set_option(name, int(val))
+    def fit_batch(want, bytes_per_read, share):
+        """reads per batch that the free device memory allows (the partition workspace and the resident reads scale with the
+        batch; a larger batch amortises the sweep of the set better): `want` unless `share` of the free bytes is less"""
+        free, _ = torch.cuda.mem_get_info(dev)
+        fit = int(share * free / bytes_per_read) // 1_000_000 * 1_000_000
+        return max(4_000_000, min(want, fit)) if wgs else want
+
+    # parent insert at whole-genome scale: three partition levels, ~2.5 KB of workspace per read of the batch
+    pbatch = min(fit_batch(wl["parent_batch"], 2500, 0.8), reads_rank)
     batch = min(wl["batch"], reads_rank)
-    pbatch = min(wl["parent_batch"], reads_rank)
     n_batches = (reads_rank + batch - 1) // batch
     n_pbatches = (reads_rank + pbatch - 1) // pbatch
 
@@ -283,6 +291,8 @@ def main():
     torch.cuda.synchronize()
     parent_seconds = time.perf_counter() - t_par
     progress("parent build done in %.1f s" % parent_seconds)
+    freed = eng.trim()                       # the child pass uses other workspace shapes: hand the parents' back first
+    progress("workspace of the parent build returned: %.1f GB" % (freed / 1e9))
     set_hint(batch)
     allreduce_ms, allreduce_bytes, allreduce_path = 0.0, 0, None
     if world > 1:
@@ -332,6 +342,10 @@ def main():
         p_err = 1.0 - (1.0 - wl["err"]) ** k
         cap = int(1.12 * p_err * reads_rank * (L - k + 1) / R)
         acc = dk.ChildAccumulator(eng, kset, capacity_records=cap, window_index=0, window_count=R)
+        # child batch: ~1.25 KB of partition workspace per read (one hash window) + 57 bytes per resident read and step
+        batch = min(fit_batch(wl["batch"], 1250 / R * 2 + 57 * (args.warmup + args.steps), 0.85), reads_rank)
+        n_batches = (reads_rank + batch - 1) // batch
+        set_hint(batch)
         n_res = min(n_batches, args.warmup + args.steps)
         resident = []
         for b in range(n_res):

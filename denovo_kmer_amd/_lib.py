@@ -80,6 +80,7 @@ SYMBOLS = {
     "dk_engine_timings": (C.c_int32, [_P, C.POINTER(DkTimings)]),
     "dk_engine_config": (C.c_int32, [_P, C.POINTER(DkConfig)]),
     "dk_engine_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
+    "dk_engine_trim": (C.c_int32, [_P, _PU64]),
     "dk_reads_from_ascii": (C.c_int32, [_P, _P, _P, _U64, _PP]),
     "dk_reads_from_packed": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),
     "dk_reads_attach_device": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),

@@ -90,6 +90,12 @@ class Engine:
         validated test hooks that force a kernel geometry ("scan_variant", "force_l3", ...)"""
         self.check(self._lib.dk_engine_set_option(self.handle, name.encode(), int(value)))
 
+    def trim(self):
+        """free the engine's cached workspace blocks now (dk_engine_trim) -> bytes freed"""
+        n = C.c_uint64()
+        self.check(self._lib.dk_engine_trim(self.handle, C.byref(n)))
+        return int(n.value)
+
     @staticmethod
     def comm_unique_id():
         """128-byte RCCL id (dk_comm_unique_id): one rank creates it, the host hands it to the others"""

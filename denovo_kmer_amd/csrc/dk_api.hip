@@ -541,6 +541,25 @@ dk_status dk_engine_config(const dk_engine *e, dk_config *out)
     return DK_OK;
 }
 
+dk_status dk_engine_trim(dk_engine *e, uint64_t *bytes_freed)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    DK_HIP(e, hipSetDevice(e->device));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    uint64_t freed = 0;
+    for (auto &b : e->pool)
+        if (!b.in_use && b.ptr) {
+            (void)hipFree(b.ptr);
+            freed += b.bytes;
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+    e->pool.erase(std::remove_if(e->pool.begin(), e->pool.end(), [](const dk_pool_block &b) { return b.ptr == nullptr; }),
+                  e->pool.end());
+    if (bytes_freed) *bytes_freed = freed;
+    return DK_OK;
+}
+
 dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
 {
     if (!e) return DK_ERR_INVALID_ARG;

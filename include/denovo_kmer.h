@@ -132,6 +132,10 @@ dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
  *   "scan_variant" 1..6, "repart_variant" 0..1, "force_l3" 0..1, "b1_up" -4..4, "count_seg" >= 64, "cnt_mid" >= 1,
  *   "sub_split" 0..3 | 9 (0 = automatic, 9 = never), "repart_plain" 0..1, "merge_pass_bits" 0..8, "merge_idx64" 0..1 */
 dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
+/* The engine keeps the device memory of finished operations in a pool for the next one (no allocation inside timed
+ * work); it hands cached blocks back by itself when an allocation fails.  dk_engine_trim frees every cached block now --
+ * between the parent build and the child pass of a whole-genome run, whose workspaces differ -- and reports the bytes freed. */
+dk_status   dk_engine_trim(dk_engine *e, uint64_t *bytes_freed);
 
 /* ---- read batches (replaces: the &[u8] read sequences handed to kmer.rs by the BAM loop) --- */
 /* ASCII reads, concatenated, offsets[n_reads+1]; packed on the GPU */
