@@ -577,6 +577,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"cnt_split_to", &dk_options::cnt_split_to, 0, 1 << 30},
         {"sub_split", &dk_options::sub_split, 0, 9},
         {"repart_plain", &dk_options::repart_plain, 0, 1},
+        {"repart_bits", &dk_options::repart_bits, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"merge_idx64", &dk_options::merge_idx64, 0, 1},
     };

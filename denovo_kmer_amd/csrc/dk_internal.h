@@ -26,6 +26,7 @@ struct dk_options {
     int cnt_mid = 0;              // seg_count: threshold of the 512-thread geometry (default 3600)
     int cnt_big = 0;              // seg_count: threshold of the 1024-thread geometry (default 7000, k > 32: 3500)
     int cnt_split_to = 0;         // absent-list split: records per unit aimed at (default 6000, k > 32: 3000)
+    int repart_bits = 0;          // repart: most hash bits one pass may take (default 10; 9 = round 1's limit, for A/B runs)
     int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
     int sub_split = 0;            // sub-segment split of the set kernels: 0 = automatic, 1..3 = force, 9 = never
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes

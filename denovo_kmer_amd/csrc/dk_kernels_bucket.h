@@ -29,8 +29,10 @@ constexpr int SEG_BYTES = SEG_BLOCKS * 64;
 constexpr int PART_THREADS = 1024;
 constexpr int PART_PER_THREAD = 8;
 constexpr int PART_TILE = PART_THREADS * PART_PER_THREAD;   // positions (or records) per tile
-constexpr int MAX_BIN_BITS = 9;
+constexpr int MAX_BIN_BITS = 9;                        // level 1 (scan_part: private pieces, the runs must stay long)
 constexpr int MAX_BINS = 1 << MAX_BIN_BITS;
+constexpr int MAX_BIN_BITS2 = 10;                      // later levels (repart: one bin per XCD, its L2 assembles the lines of short runs)
+constexpr int MAX_BINS2 = 1 << MAX_BIN_BITS2;
 constexpr int MAX_SEG_BITS = 23;                       // two levels up to 18 bits, three levels beyond (coarse regions <= 2^15: grid y)
 constexpr int CURSOR_STRIDE = 32;                      // level-1 cursors on separate 128-B lines
 
@@ -160,14 +162,14 @@ __device__ __forceinline__ void ovf_append(const OvfList<R> &ovf, bool pred, con
 // out as per-bin runs.  Three barriers per tile (A: counts done - by the caller, B: offsets ready,
 // C: stage ready); the next tile's count phase needs no barrier because it touches only cnt[],
 // which wave 0 re-zeroes before B.
-template <int THREADS, int PER_THREAD, class R>
+template <int THREADS, int PER_THREAD, class R, int NB = MAX_BINS, bool PRIVATE = true>
 struct SplitLds {
     R stage[THREADS * PER_THREAD];
-    uint32_t cnt[MAX_BINS];     // per-tile counts; zero on entry to every count phase
-    uint32_t off[MAX_BINS];     // tile offset of each bin in stage[]
-    uint32_t delta[MAX_BINS];   // index in the piece = stage index + delta[bin]  (mod 2^32)
-    uint32_t cur[MAX_BINS];     // running fill of this workgroup's piece of each bin
-    unsigned long long gptr[MAX_BINS];   // scan_part: byte address of (piece slot of stage index 0) per bin
+    uint32_t cnt[NB];           // per-tile counts; zero on entry to every count phase
+    uint32_t off[NB];           // tile offset of each bin in stage[]
+    uint32_t delta[NB];         // index in the piece = stage index + delta[bin]  (mod 2^32)
+    uint32_t cur[PRIVATE ? NB : 1];              // scan_part: running fill of this workgroup's piece of each bin
+    unsigned long long gptr[PRIVATE ? NB : 1];   // scan_part: byte address of (piece slot of stage index 0) per bin
     uint32_t total;
     uint32_t ovf_seen;          // some bin of this workgroup has run past its capacity (never cleared)
 };
@@ -562,7 +564,8 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
               uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0)
 {
     constexpr int TILE = THREADS * PER_THREAD;
-    __shared__ SplitLds<THREADS, PER_THREAD, R> L;
+    constexpr int NB = THREADS >= MAX_BINS2 ? MAX_BINS2 : MAX_BINS;      // the bin scan is one thread per bin
+    __shared__ SplitLds<THREADS, PER_THREAD, R, NB, false> L;
     const int tid = (int)threadIdx.x;
     // one-dimensional grid (the number of bins can exceed the 65535 of grid.y): bin-major, then piece, then tile
     const uint32_t per_bin = G * tiles_per_piece;
@@ -582,7 +585,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     const int nbins = 1 << b2;
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
-    for (int i = tid; i < MAX_BINS; i += THREADS) L.cnt[i] = 0;
+    for (int i = tid; i < NB; i += THREADS) L.cnt[i] = 0;
     if (tid == 0) L.ovf_seen = 0;
     const R *src = in + piece * capw;
     R hs[PER_THREAD];
@@ -613,7 +616,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         c_mine = c;
         uint32_t below = 0;
 #pragma unroll
-        for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
+        for (int v = 0; v < NB / 64 - 1; v++) {
             const uint32_t x = L.cnt[64 * v + lane];
             below += v < wv ? x : 0u;
         }
@@ -1606,7 +1609,9 @@ inline int pick_sub_bits(const dk_engine *e, int T_local)
     if (o >= 1 && o <= 3) return T_local - o >= 1 ? o : 0;
     // (one bit only: four workgroups re-reading a region cost seg_insert more than the third pass -- 50.7 vs 34.8 + 19.7 ms
     // per 48 M reads at 2^39 bits)
-    return T_local == 2 * MAX_BIN_BITS + 1 ? 1 : 0;
+    const bool wide = e->cfg.k > 32;
+    const int two = MAX_BIN_BITS + (wide ? MAX_BIN_BITS : (e->opt.repart_bits > 0 ? e->opt.repart_bits : MAX_BIN_BITS2));
+    return T_local == two + 1 ? 1 : 0;
 }
 
 // T_override > 0: number of segment bits to use instead of the filter's.  wbits > 0: only the records of one
@@ -1621,7 +1626,8 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     if (p->T < 1 || p->T > MAX_SEG_BITS) return false;
     p->b3 = 0;
     p->capA = 0;
-    if (p->T > 2 * MAX_BIN_BITS || (e->opt.force_l3 && p->T >= 3)) {
+    const int bits2 = wide ? MAX_BIN_BITS : (e->opt.repart_bits > 0 ? e->opt.repart_bits : MAX_BIN_BITS2);   // k > 32: 512-thread repart
+    if (p->T > MAX_BIN_BITS + bits2 || (e->opt.force_l3 && p->T >= 3)) {
         // three levels: thirds of T; the coarse regions (b1 + b2 bits) index the grid's y dimension
         p->b1 = p->T / 3;
         p->b2 = (p->T - p->b1) / 2;
@@ -1629,7 +1635,7 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     } else {
         p->b1 = (p->T + e->opt.b1_up) / 2;
         if (p->b1 > MAX_BIN_BITS) p->b1 = MAX_BIN_BITS;
-        if (p->T - p->b1 > MAX_BIN_BITS) p->b1 = p->T - MAX_BIN_BITS;
+        if (p->T - p->b1 > bits2) p->b1 = p->T - bits2;
         p->b2 = p->T - p->b1;
     }
     int v = scan_variant(e, p->b1, wbits > 0);
@@ -1637,7 +1643,7 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
         // a forced geometry with fewer threads than level-1 bins (the bin scan is one thread per bin): move bits to level 2
         int t = 0;
         while ((2 << t) <= scan_variant_threads(v)) t++;
-        if (p->T - t > MAX_BIN_BITS) v = scan_variant(e, p->b1, true);   // cannot: fall back to the automatic geometry
+        if (p->T - t > bits2) v = scan_variant(e, p->b1, true);   // cannot: fall back to the automatic geometry
         else { p->b1 = t; p->b2 = p->T - t; }
     }
     p->variant = v;

@@ -753,15 +753,16 @@ def test_three_level_partition_forced_on_small_inputs():
     _forced_geometry_trio({"force_l3": 1}, ["scan_part", "repart", "repart3"])
 
 
-@pytest.mark.parametrize("set_kind", ["bloom", "exact"])
-def test_three_level_partition_at_2_to_the_38_bits(set_kind):
-    """A 32-GiB parent set (2^19 segments): the bucketed family inserts through two levels + the sub-segment split and
-    probes a single batch through three levels; the direct family,
-    an independent implementation working on the same geometry, must agree on the set size and on every
-    child-only k-mer and count (the oracle cannot hold a 32-GiB filter in this test's time)."""
+@pytest.mark.parametrize("set_kind,log2_bits", [("bloom", 38), ("exact", 38), ("bloom", 40)])
+def test_partition_levels_of_very_large_sets(set_kind, log2_bits):
+    """32-GiB and 128-GiB parent sets.  2^38 bits = 2^19 segments: two partition levels (512 x 1024 bins).  2^40 bits =
+    2^21 segments: three levels.  The direct family, an independent implementation working on the same geometry, must
+    agree on the set size and on every child-only k-mer and count (the oracle cannot hold such a filter in this test's
+    time)."""
     d = dk()
-    n_reads, k, log2_bits = 1_500_000, 31, 38
+    n_reads, k = 1_500_000, 31
     gcfg = d.synth_config(genome_len=8 << 20)
+    levels = ["scan_part", "repart"] + (["repart3"] if log2_bits >= 40 else [])
     out = {}
     for mode in ("bucketed", "direct"):
         with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=20260313, mode=mode, set_kind=set_kind) as eng:
@@ -770,14 +771,13 @@ def test_three_level_partition_at_2_to_the_38_bits(set_kind):
                 ks.insert_reads(d.ReadBatch.synth(eng, gcfg, smp, 0, n_reads))
             names = [n for n, _ in eng.timings()["stages"]]
             if mode == "bucketed":
-                # 2^19 segments: two partition levels to 2^18 regions, the insert kernel of each segment takes its half
-                assert names[:2] == ["scan_part", "repart"] and "repart3" not in names, names
+                assert names[:len(levels)] == levels and ("repart3" in names) == (log2_bits >= 40), names
             else:
                 assert names == ["insert_direct"], names
             pop = ks.popcount()
             res = d.KmerCounter(eng).child_only(d.ReadBatch.synth(eng, gcfg, 2, 0, n_reads), ks)
             names = [n for n, _ in eng.timings()["stages"]]
-            assert (names[:3] == ["scan_part", "repart", "repart3"]) if mode == "bucketed" else names[0] == "probe_direct", names
+            assert (names[:len(levels)] == levels) if mode == "bucketed" else names[0] == "probe_direct", names
             out[mode] = (pop, {key: res.stats[key] for key in ("n_windows", "n_valid", "n_absent", "n_distinct", "n_emitted")},
                          _result_checksum(res))
             res.close()
