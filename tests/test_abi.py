@@ -103,3 +103,35 @@ def test_product_code_never_imports_the_oracle():
                     if re.search(r"(from|import)\s+oracle|dk_oracle|orc_", text):
                         bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_malformed_read_batches_are_rejected():
+    """ASCII offsets must start at 0; a packed stream (uploaded or attached) must end with a flagged separator
+    position -- the kernels judge a window that would run past the end by its mask flags"""
+    import denovo_kmer_amd as d
+    from denovo_kmer_amd.api import pack_ascii_host
+    with d.Engine(k=21, filter_log2_bits=22) as eng:
+        seq = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTAAAA", dtype=np.uint8).copy()
+        with pytest.raises(d.DkError) as ei:
+            d.ReadBatch.from_ascii(eng, seq, np.array([4, 28], dtype=np.uint64))
+        assert ei.value.status == _lib.DK_ERR_INVALID_ARG and "offsets[0]" in str(ei.value)
+        with pytest.raises(d.DkError):
+            d.ReadBatch.from_ascii(eng, seq, np.array([0, 20, 10], dtype=np.uint64))        # not monotonic
+        bases, mask, n = pack_ascii_host(seq, np.array([0, 28], dtype=np.uint64))
+        ok = d.ReadBatch.from_packed(eng, bases, mask, n, 1, 8)
+        assert ok.stats()["n_bases"] == 29
+        bad_mask = mask.copy()
+        bad_mask[(n - 1) >> 6] &= ~np.uint64(1 << (63 - ((n - 1) & 63)))                     # clear the final separator flag
+        with pytest.raises(d.DkError) as ei:
+            d.ReadBatch.from_packed(eng, bases, bad_mask, n, 1, 8)
+        assert "separator" in str(ei.value)
+        tb = torch.from_numpy(bases.view(np.int64)).cuda()
+        tm = torch.from_numpy(bad_mask.view(np.int64)).cuda()
+        with pytest.raises(d.DkError) as ei:
+            d.ReadBatch.attach_device(eng, tb.data_ptr(), tm.data_ptr(), n, 1, 8, keepalive=(tb, tm))
+        assert "separator" in str(ei.value)
+        tm2 = torch.from_numpy(mask.view(np.int64)).cuda()
+        att = d.ReadBatch.attach_device(eng, tb.data_ptr(), tm2.data_ptr(), n, 1, 8, keepalive=(tb, tm2))
+        ks = d.KmerSet(eng)
+        assert ks.insert_reads(att)["n_valid"] == 8
