@@ -252,3 +252,41 @@ def test_min_count_table_too_small_is_recounted_exactly():
         assert res.stats["n_distinct"] == ost["n_distinct"] == len(lo)
         res.close()
         acc.close()
+
+
+@pytest.mark.parametrize("window_count", [1, 2])
+def test_heavy_hitters_reach_the_accumulator_through_the_overflow_paths(window_count):
+    """hundreds of thousands of copies of one absent k-mer overflow their partition region (handled one by one:
+    ovf_probe -> ovf_append) and then their counting unit (the accumulator's overflow list, sorted in at finish);
+    a k-mer that is present in the set overflows the region too and must not be counted"""
+    d = dk()
+    k = 21
+    parents = ["A" * 150] * 2000 + ["ACGTTGCATGCCGATAGCTAGCTAGGATCGATCGATTAGC" * 3] * 10
+    child = ["A" * 150] * 3000 + ["C" * 150] * 3000 + parents[-10:] + ["GATTACA" * 20] * 5
+    pseq, poff = orc.concat_reads(parents)
+    cseq, coff = orc.concat_reads(child)
+    f = orc.new_filter(24)
+    orc.bloom_insert(f, 24, 4, 5, k, True, pseq, poff)
+    with d.Engine(k=k, filter_log2_bits=24, n_hashes=4, seed=5, mode="bucketed") as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(parents)
+        # (the overflow list holds capacity / 64 entries: room for the 390 000 copies of poly-C beyond their unit)
+        acc = d.ChildAccumulator(eng, ks, capacity_records=30_000_000, window_count=window_count)
+        for mc in (1, 100):
+            km, cn, ost = orc.bloom_probe(f, 24, 4, 5, k, True, cseq, coff, mc)
+            got, seen_ovf = {}, False
+            for w in range(window_count):
+                acc.reset(w)
+                for b in ragged_batches(child, (0.3, 0.7)):
+                    acc.add(d.ReadBatch.from_sequences(eng, b))
+                    names = [n for n, _ in eng.timings()["stages"]]
+                    assert "overflow_redo" not in names, names
+                    seen_ovf = seen_ovf or "ovf_append" in names
+                res = acc.finish(min_count=mc)
+                got.update(table_of(res))
+                res.close()
+            assert seen_ovf, "the poly-C batch was expected to overflow its partition region"
+            assert got == oracle_table(km, cn)
+            assert max(got.values()) == 3000 * 130
+        acc.close()
+        ks.close()
