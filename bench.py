@@ -445,6 +445,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_child_only, n_absent_all, child_windows, gen_s = 0, 0, 0, 0.0
+        add_dev_ms, finish_dev_ms, finish_stage_ms = 0.0, 0.0, {}
         for w in range(R):
             acc.reset(w)
             for b in range(n_batches):
@@ -453,10 +454,15 @@ def main():
                 cb = dk.ReadBatch.synth(eng, gcfg, 2, lo, n)      # generated in place (a real host would upload packed reads here)
                 gen_s += time.perf_counter() - tg
                 st = acc.add(cb)
+                add_dev_ms += eng.timings()["total_ms"]
                 if w == 0:
                     child_windows += st["n_windows"]
                 cb.close()
             res = accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
+            tf = eng.timings()
+            finish_dev_ms += tf["total_ms"]
+            for name, ms in tf["stages"]:
+                finish_stage_ms[name] = finish_stage_ms.get(name, 0.0) + ms
             progress("end to end: pass %d of %d counted" % (w + 1, R))
             n_child_only += len(res)
             n_absent_all += res.stats["n_absent"]
@@ -476,6 +482,8 @@ def main():
                "child_seconds_without_read_generation": child_seconds - gen_s,
                "child_gkmers_s": child_windows / (child_seconds - gen_s) / 1e9,
                "hash_windows": R, "batches_per_pass": n_batches, "min_count": wl["min_count"],
+               "device_seconds_adds": add_dev_ms * 1e-3, "device_seconds_counting": finish_dev_ms * 1e-3,
+               "counting_stages_ms": finish_stage_ms,
                "absent_occurrences": n_absent_all, "child_only_kmers": n_child_only,
                "trio_seconds": parent_seconds + allreduce_ms * 1e-3 + child_seconds,
                "trio_gkmers_s": (parent_windows + child_windows) / (parent_seconds + allreduce_ms * 1e-3 + child_seconds) / 1e9,

@@ -241,7 +241,7 @@ void      dk_result_destroy(dk_result *res);
  * equal ranges; every pass touches 1/window_count of the set and of the partition workspace, and the union of the
  * passes' tables is the whole result (the ranges are disjoint).
  *   capacity_records  expected number of absent occurrences per pass (slack for the spread between groups is added
- *                     inside: the store takes ~1.3 x 8 bytes x capacity); occurrences beyond a group's room go to
+ *                     inside: the store takes ~1.1 x 8 bytes x capacity); occurrences beyond a group's room go to
  *                     an overflow list of capacity/64 entries, and DK_ERR_OVERFLOW is returned once that is full
  *                     (the accumulator is then unusable until dk_accum_reset; use more windows or a larger capacity)
  *   s == NULL         every k-mer counts (KmerCounter over a sample in batches) */
