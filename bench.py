@@ -344,6 +344,11 @@ def main():
         acc = dk.ChildAccumulator(eng, kset, capacity_records=cap, window_index=0, window_count=R)
         # child batch: ~1.25 KB of partition workspace per read (one hash window) + 57 bytes per resident read and step
         batch = min(fit_batch(wl["batch"], 1250 / R * 2 + 57 * (args.warmup + args.steps), 0.85), reads_rank)
+        if world > 1:
+            # the counting passes inside the loops below are collective: every rank must walk the same number of batches
+            bt = torch.tensor([batch], dtype=torch.int64, device=sdev)
+            dist.all_reduce(bt, op=dist.ReduceOp.MIN)
+            batch = int(bt.item())
         n_batches = (reads_rank + batch - 1) // batch
         set_hint(batch)
         n_res = min(n_batches, args.warmup + args.steps)
