@@ -167,9 +167,16 @@ def comm_init_from_torch(engine, group=None):
     all-reduce natively on the engine's stream -- the path a Rust host takes (it has no torch)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    box = [engine.comm_unique_id() if rank == 0 and world > 1 else None]
+    box = [None]
+    if rank == 0 and world > 1:
+        try:
+            box = [engine.comm_unique_id()]
+        except Exception as exc:            # noqa: BLE001 -- librccl missing: every rank must learn it, none may wait for an id
+            box = [str(exc)]
     if world > 1:
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError("no RCCL communicator: %s" % (box[0],))
     engine.comm_init(box[0], rank, world)
 
 
