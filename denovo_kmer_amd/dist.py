@@ -118,6 +118,12 @@ def accum_exchange_finish(acc, min_count=1, group=None, stage_through_cpu=False)
     dev = torch.device("cuda", eng.device_id)
     n_units, cap, rb = acc.geometry()
     assert n_units % world == 0, "the units of a window split evenly over a power-of-two number of ranks"
+    # the slices are interpreted with THIS rank's geometry: every rank must have created its accumulator alike
+    geo = torch.tensor([n_units, -n_units, cap, -cap, rb, -rb], dtype=torch.int64, device="cpu" if stage_through_cpu else dev)
+    dist.all_reduce(geo, op=dist.ReduceOp.MAX, group=group)
+    if any(int(geo[i]) != -int(geo[i + 1]) for i in (0, 2, 4)):
+        raise ValueError("accumulators differ between ranks (units, unit capacity or record size): create them with the "
+                         "same capacity_records and window_count on every rank")
     upr = n_units // world
     sp, fp, op, n_ovf = acc.device_view()
     store = _device_bytes(sp, n_units * cap * rb, dev).view(world, upr * cap * rb)
