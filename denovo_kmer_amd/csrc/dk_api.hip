@@ -1435,15 +1435,17 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
     a->T = T;
     a->u = u;
     a->n_units = n_seg_w << u;
-    // room per unit = mean + 6 sigma of a Poisson fill + 64: absent occurrences are sequencing errors, i.e. independent;
+    // room per unit = mean + 5 sigma of a Poisson fill: absent occurrences are sequencing errors, i.e. independent;
     // a unit that still runs full sends the rest to the overflow list, which is counted with it (exact either way)
     {
         const double mean = (double)capacity_records / (double)a->n_units;
-        a->unit_cap = (uint32_t)(mean + 6.0 * sqrt(mean + 1.0) + 64.0);
         // unit stride = a multiple of 4 KiB plus 128 bytes: the count kernel's workgroups read consecutive units at the same
         // time, and strides that sit near a large power of two pile those reads onto few HBM channels (measured on the
-        // 9.6 x 10^9 records of a whole-genome pass: 66 ms at 12 304 records per unit, 150 ms at 11 758, 217 ms at 12 288)
-        a->unit_cap = (a->unit_cap + 511) / 512 * 512 + 16;
+        // 9.6 x 10^9 records of a whole-genome pass: 66 ms at 12 304 records per unit, 150 ms at 11 758, 217 ms at 12 288).
+        // The smallest such capacity that leaves 5 sigma of room (the rare unit beyond it spills to the overflow list).
+        const uint32_t rec_bytes = wide ? 16u : 8u, per_4k = 4096u / rec_bytes, odd = 128u / rec_bytes;
+        const uint32_t need = (uint32_t)(mean + 5.0 * sqrt(mean + 1.0)) + 1u;
+        a->unit_cap = (need > odd ? (need - odd + per_4k - 1) / per_4k * per_4k : 0u) + odd;
     }
     a->wide = wide;
     a->store = nullptr;
