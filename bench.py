@@ -238,11 +238,12 @@ def main():
     for ov in args.opt:
         name, _, val = ov.partition("=")
         eng.set_option(name, int(val))
-    def fit_batch(want, bytes_per_read, share):
+    def fit_batch(want, bytes_per_read, share, reserve=0):
         """reads per batch that the free device memory allows (the partition workspace and the resident reads scale with the
-        batch; a larger batch amortises the sweep of the set better): `want` unless `share` of the free bytes is less"""
+        batch; a larger batch amortises the sweep of the set better): `want` unless `share` of the free bytes (less
+        `reserve`, set aside for later allocations) is less"""
         free, _ = torch.cuda.mem_get_info(dev)
-        fit = int(share * free / bytes_per_read) // 1_000_000 * 1_000_000
+        fit = int(share * max(free - reserve, 0) / bytes_per_read) // 1_000_000 * 1_000_000
         return max(4_000_000, min(want, fit)) if wgs else want
 
     # parent insert at whole-genome scale: three partition levels, ~2.5 KB of workspace per read of the batch
@@ -343,7 +344,9 @@ def main():
         cap = int(1.12 * p_err * reads_rank * (L - k + 1) / R)
         acc = dk.ChildAccumulator(eng, kset, capacity_records=cap, window_index=0, window_count=R)
         # child batch: ~1.25 KB of partition workspace per read (one hash window) + 57 bytes per resident read and step
-        batch = min(fit_batch(wl["batch"], 1250 / R * 2 + 57 * (args.warmup + args.steps), 0.85), reads_rank)
+        # (N > 1: the pieces received from the other ranks before counting take as much room as the accumulator itself)
+        batch = min(fit_batch(wl["batch"], 1250 / R * 2 + 57 * (args.warmup + args.steps), 0.85,
+                              reserve=acc.device_bytes() * 1.05 if world > 1 else 0), reads_rank)
         if world > 1:
             # the counting passes inside the loops below are collective: every rank must walk the same number of batches
             bt = torch.tensor([batch], dtype=torch.int64, device=sdev)
