@@ -96,7 +96,9 @@ struct Stamps {
 #endif
 };
 
-// exclusive prefix sum over the block; every thread calls it; *total gets the block sum
+// exclusive prefix sum over the block; every thread calls it; *total gets the block sum.
+// LDS_ONLY: the barriers order LDS traffic only (lds_barrier), for kernels with global stores in flight
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_sums, uint32_t *total)
 {
     const int lane = lane_id();
@@ -104,14 +106,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wave_s
     const int n_waves = (int)(blockDim.x >> 6);
     const uint32_t inc = wave_incl_scan(v);
     if (lane == 63) wave_sums[wave] = inc;
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     if (wave == 0) {
         const uint32_t w = lane < n_waves ? wave_sums[lane] : 0;
         const uint32_t wi = wave_incl_scan(w);
         if (lane < n_waves) wave_sums[lane] = wi - w;       // exclusive wave offsets
         if (lane == n_waves - 1) *total = wi;
     }
-    __syncthreads();
+    if (LDS_ONLY) lds_barrier(); else __syncthreads();
     return wave_sums[wave] + inc - v;
 }
 
@@ -1137,7 +1139,7 @@ union_slices_kernel(unsigned long long *dst, const unsigned long long *__restric
 // Two geometries: <512 threads, 2048 slots, 64-Kbit bitmaps> for segments with thousands of absent
 // records, <128, 512, 8 Kbit> (8 KB of LDS, many workgroups per CU) when a segment holds a few hundred.
 template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE>
-__global__ void __launch_bounds__(CNT_THREADS)
+__global__ void __launch_bounds__(CNT_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
                  uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
                  uint32_t *__restrict__ out_cnt, Counters *ctr, uint64_t unit_base)
@@ -1145,6 +1147,8 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     // unit_base: the units counted are unit_base .. unit_base + n_seg of the 2^T hash-prefix ranges (a window of
     // an accumulator).  Entries beyond a region's capacity are not written but still tallied in region_fill (and
     // flagged through n_overflow), so a table sized too small tells how large it has to be.
+    // Every barrier of this kernel orders LDS traffic only (lds_barrier): records are read-only, results write-only, and
+    // a __syncthreads() would make every unit wait until the result stores of the previous phase have left the CU.
     using R = typename RecOf<WIDE>::type;
     constexpr int CNT_RPT = (WIDE && CNT_THREADS < 1024) ? 8 : 16;   // records held per thread (the 1024-thread geometry runs one workgroup per CU: 128 VGPRs)
     constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
@@ -1159,6 +1163,9 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     __shared__ uint32_t wave_sums[CNT_THREADS / 64];
     __shared__ uint32_t total;
     __shared__ unsigned long long gbase;
+    constexpr bool GATHER = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no registers to spare)
+    constexpr uint32_t WB = WIDE ? 32 : 64;              // per wave: flagged records gathered for one dense trip through the table
+    __shared__ R wbuf[GATHER ? CNT_THREADS / 64 : 1][WB];
     const int tid = (int)threadIdx.x;
     const int wave = tid >> 6;
     uint32_t n_distinct = 0, n_fail = 0;
@@ -1208,7 +1215,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
         for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
         if (single) load_chunk(0);
-        __syncthreads();
+        lds_barrier();
         // pass 1: mark
         for (uint32_t c = 0; c < n_chunks; c++) {
             if (!single) load_chunk(c);
@@ -1221,7 +1228,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // pass 2: classify; per-wave count of provably unique records, block count of flagged ones
         uint32_t my_unique = 0, my_flagged = 0;
         for (uint32_t c = 0; c < n_chunks; c++) {
@@ -1247,12 +1254,12 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         };
         const uint32_t emit_unique = min_count <= 1 ? 1u : 0u;
         const uint32_t wave_unique = wave_total(my_unique);          // uniform per wave
-        (void)block_excl_scan(my_flagged, wave_sums, &total);
+        (void)block_excl_scan<true>(my_flagged, wave_sums, &total);
         const uint32_t n_flagged = total;
-        __syncthreads();
+        lds_barrier();
         // bases of the waves' unique runs: prefix over the per-wave totals
         if ((tid & 63) == 0) wave_sums[wave] = wave_unique;
-        __syncthreads();
+        lds_barrier();
         uint32_t wave_base = 0, all_unique = 0;
 #pragma unroll
         for (int v = 0; v < CNT_THREADS / 64; v++) {
@@ -1262,7 +1269,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         }
         n_distinct += (tid == 0) ? all_unique : 0;
         if (tid == 0) gbase = (emit_unique && all_unique) ? atomicAdd(fill, (unsigned long long)all_unique) : 0ULL;
-        __syncthreads();
+        lds_barrier();
         // pass 3: emit the unique records, each wave a contiguous run, compacted by ballot
         if (emit_unique && all_unique) {
             uint64_t o = gbase + wave_base;
@@ -1297,12 +1304,75 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             uint32_t rounds = (n_flagged + 4 * slots - 1) / (4 * slots);
             uint32_t r = 0;
             while (r < rounds) {
-                __syncthreads();
+                lds_barrier();
                 for (uint32_t i = tid; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
                 if (tid == 0) total = 0;                       // doubles as the "round does not fit" flag
-                __syncthreads();
+                lds_barrier();
                 for (int phase = 0; phase < (WIDE ? 2 : 1); phase++) {
                     // phase 0: insert and count.  phase 1 (k > 32): re-check the full key of every record
+                    if (GATHER && single) {
+                        // Records in registers.  Flagged records are few per register slot (~10 % of the lanes when nearly every
+                        // k-mer is unique), and a trip through the table is a chain of LDS round trips: going slot by slot
+                        // cost eight (sixteen) chains per wave with a handful of lanes each -- half of the kernel's time.  The
+                        // wave gathers its flagged records in a 64-entry LDS buffer instead and walks the table with all
+                        // lanes busy, once per 64 records.
+                        R *const wb = wbuf[GATHER ? wave : 0];
+                        auto walk = [&](uint32_t cnt) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t lane = (uint32_t)lane_id();
+                            bool active = lane < cnt;
+                            const R cur = wb[lane & (WB - 1)];
+                            const unsigned long long f = fp_of(cur);
+                            uint32_t slot = (uint32_t)(f >> 8) & slot_mask, tries = 0;
+                            while (__any(active)) {
+                                if (active) {
+                                    if (phase == 0) {
+                                        const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, f);
+                                        if (prev == EMPTY) {
+                                            if constexpr (WIDE) { key_h[slot] = cur.h; key_hi[slot] = rec_hi(cur); }
+                                        }
+                                        if (prev == EMPTY || prev == f) {
+                                            atomicAdd(&cnts[slot], 1u);
+                                            active = false;
+                                        } else {
+                                            slot = (slot + 1) & slot_mask;
+                                            if (++tries == 64) { total = 1; active = false; }      // too crowded: split this round
+                                        }
+                                    } else {
+                                        if (keys[slot] == f) {
+                                            if (key_h[slot] != cur.h || key_hi[slot] != rec_hi(cur)) n_fail++;
+                                            active = false;
+                                        } else {
+                                            slot = (slot + 1) & slot_mask;
+                                            if (++tries == 64) { n_fail++; active = false; }
+                                        }
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        };
+                        uint32_t held = 0;                                 // records in the wave's buffer (wave-uniform)
+#pragma unroll
+                        for (int u = 0; u < CNT_RPT; u++) {
+                            bool want = have(0, u) && flagged(u, hv[u]);
+                            if (want && rounds > 1) {
+                                const unsigned long long fu = fp_of(hv[u]);
+                                want = (uint32_t)((((fu >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20) == r;
+                            }
+#pragma unroll
+                            for (uint32_t part = 0; part < 64 / WB; part++) {          // at most WB records join at a time
+                                const bool mine = want && (WB == 64 || (uint32_t)lane_id() / WB == part);
+                                const uint64_t m = __ballot(mine);
+                                const uint32_t c = (uint32_t)__popcll(m);
+                                if (c == 0) continue;
+                                if (held + c > WB) { walk(held); held = 0; }
+                                if (mine) wb[held + (uint32_t)popc_below(m)] = hv[u];
+                                held += c;
+                            }
+                        }
+                        if (held) walk(held);
+                    } else
                     for (uint32_t c = 0; c < n_chunks; c++) {
                         if (!single) load_chunk(c);
 #pragma unroll
@@ -1331,7 +1401,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                             }
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     if (total) break;
                 }
                 if (total) {
@@ -1343,9 +1413,9 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 uint32_t mine = 0;
                 for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS)
                     if (keys[sl] != EMPTY) { n_distinct++; if (cnts[sl] >= min_count) mine++; }
-                const uint32_t ex = block_excl_scan(mine, wave_sums, &total);
+                const uint32_t ex = block_excl_scan<true>(mine, wave_sums, &total);
                 if (tid == 0) gbase = total ? atomicAdd(fill, (unsigned long long)total) : 0ULL;
-                __syncthreads();
+                lds_barrier();
                 uint64_t o = gbase + ex;
                 for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS) {
                     if (keys[sl] != EMPTY && cnts[sl] >= min_count) {
@@ -1367,7 +1437,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 r++;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     n_distinct = (uint32_t)wave_sum(n_distinct);
     n_fail = (uint32_t)wave_sum(n_fail);
