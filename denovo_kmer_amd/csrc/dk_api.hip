@@ -579,6 +579,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"repart_plain", &dk_options::repart_plain, 0, 1},
         {"repart_bits", &dk_options::repart_bits, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
+        {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"merge_idx64", &dk_options::merge_idx64, 0, 1},
     };
     for (const Opt &o : opts) {

@@ -2076,15 +2076,84 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B);
     PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
+    // (a seg_count workgroup holds 16 K records of 8 bytes, 8 K of 16; k > 32: units of ~3.3 K records for the 512-thread
+    // count kernel, whose registers hold 4 K: 26.6 ms against 33.6 ms with units of 1.6 K and 45 ms with the 1024-thread
+    // kernel on the configs[4] batch)
+    const uint64_t split_above = WIDE ? 7000 : 14000, split_to = e->opt.cnt_split_to > 0 ? (uint64_t)e->opt.cnt_split_to : (WIDE ? 3400 : 6000);
+    int Tc = p.T;
+    bool sunk_fine = false;                   // the absent records went straight into finer counting units
     if (st == DK_OK && s) {
         const uint32_t miss_cap = p.cap2;
         const MissOut<R> mo{B.scratch, miss_cap, B.miss_cnt, 0, 0, OvfList<R>{nullptr, nullptr, 0}};
-        const hipError_t h = launch_seg_probe<R, false>(e, s, list, p.n_seg, p.T, 0, mo);
-        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
-        else stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
-        list = PieceList<R>{B.scratch, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
+        // Big batches against a small filter can leave more absent records per segment than a seg_count workgroup
+        // holds in registers.  Where the segments are large enough for that, the first 64 of them are probed on their own
+        // (hashes spread evenly: they tell the absent rate of the batch to a few per cent); if the rate is that high, the
+        // membership kernel appends every segment's absent records to 2^u finer units by the next u hash bits, as it does
+        // for an accumulator, and they are counted from there -- no second pass over the absent lists (count_split below,
+        // which stays as the fallback for a unit that runs full).
+        int u = 0;
+        const uint64_t n_sample = 64;
+        if (p.cap2 > split_above && p.n_seg > 2 * n_sample && !e->opt.sink_plain) {
+            hipError_t h = launch_seg_probe<R, false>(e, s, list, n_sample, p.T, 0, mo);
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
+            if (st == DK_OK) st = sync_counters(e, "membership sample");
+            if (st == DK_OK) {
+                const uint64_t est = e->h_ctr->n_absent / n_sample;
+                e->h_ctr->n_absent = 0;
+                h = hipMemsetAsync(&e->d_ctr->n_absent, 0, 8, e->stream);
+                if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h));
+                if (est > split_above) {
+                    u = 1;
+                    while (u < MAX_SUB_BITS && (est >> u) > split_to) u++;
+                    if (p.T + u > MAX_SEG_BITS) u = 0;
+                }
+                if (st == DK_OK && u) {
+                    const uint64_t n_fine = p.n_seg << u;
+                    const double per_seg = std::min(1.1 * (double)est + 64.0, (double)e->h_ctr->n_valid / (double)p.n_seg);
+                    // same stride rule as the accumulator's units (dk_accum_create): a multiple of 4 KiB plus 128 bytes
+                    const uint32_t per_4k = 4096u / (uint32_t)sizeof(R), odd = 128u / (uint32_t)sizeof(R);
+                    const uint32_t need = piece_capacity(per_seg / (double)(1u << u), 16.0);
+                    const uint32_t cap_u = (need > odd ? (need - odd + per_4k - 1) / per_4k * per_4k : 0u) + odd;
+                    R *store = B.scratch;
+                    st = pool_alloc(e, n_fine * 4, (void **)&B.fine_cursor);
+                    if (st == DK_OK && n_fine * (uint64_t)cap_u > p.n_seg * (uint64_t)p.cap2) {
+                        st = pool_alloc(e, n_fine * (uint64_t)cap_u * sizeof(R), (void **)&B.fine);
+                        store = B.fine;
+                    }
+                    if (st == DK_OK) {
+                        h = hipMemsetAsync(B.fine_cursor, 0, n_fine * 4, e->stream);
+                        // a record whose unit is full only bumps n_overflow (no overflow list): the batch is then probed again
+                        // the plain way
+                        const MissOut<R> mf{store, cap_u, B.fine_cursor, u, 64 - p.T - u, OvfList<R>{nullptr, &e->d_ctr->dbg[0], 0}};
+                        if (h == hipSuccess) h = launch_seg_probe<R, true>(e, s, list, p.n_seg, p.T, 0, mf);
+                        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
+                    }
+                    if (st == DK_OK) {
+                        stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
+                        st = sync_counters(e, "bucketed probe");
+                        if (st == DK_ERR_OVERFLOW) {
+                            e->h_ctr->n_overflow = 0;
+                            e->h_ctr->n_absent = 0;
+                            h = hipMemsetAsync(&e->d_ctr->n_overflow, 0, 8, e->stream);
+                            if (h == hipSuccess) h = hipMemsetAsync(&e->d_ctr->n_absent, 0, 8, e->stream);
+                            st = h == hipSuccess ? DK_OK : fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h));
+                        } else if (st == DK_OK) {
+                            sunk_fine = true;
+                            list = PieceList<R>{store, B.fine_cursor, 1, cap_u, nullptr, nullptr};
+                            Tc = p.T + u;
+                        }
+                    }
+                }
+            }
+        }
+        if (st == DK_OK && !sunk_fine) {
+            const hipError_t h = launch_seg_probe<R, false>(e, s, list, p.n_seg, p.T, 0, mo);
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
+            else stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
+            list = PieceList<R>{B.scratch, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
+        }
     }
-    if (st == DK_OK) st = sync_counters(e, "bucketed probe");
+    if (st == DK_OK && !sunk_fine) st = sync_counters(e, "bucketed probe");
     uint64_t n_absent = 0;
     if (st == DK_OK) {
         if (!s) e->h_ctr->n_absent = e->h_ctr->n_valid - e->h_ctr->n_ovf;   // KmerCounter: every record in a segment counts
@@ -2093,9 +2162,8 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     // Counting units: with few absent records per filter segment (2^18 segments and more) up to four adjacent
     // segments are counted together -- their absent lists are the "pieces" of one unit, their hashes share the
     // top T - g bits -- so that seg_count sees ~3 K records per unit instead of a few hundred
-    int Tc = p.T;
     uint32_t unit_pieces = 1;
-    if (st == DK_OK && s) {
+    if (st == DK_OK && s && !sunk_fine) {
         while (unit_pieces < (uint32_t)MAX_R && Tc > 1 && (n_absent >> Tc) < 1200) {
             Tc--;
             unit_pieces *= 2;
@@ -2149,11 +2217,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
     // in registers (16 K), and its multi-chunk path is slow (150 ms at 16 K per segment).  The absent lists are
     // then split once more by the next hash bits -- the level-3 use of repart, over the absent lists instead of
     // coarse regions -- into units of ~5 K records; the space of the probed records is free for the result.
-    // (a seg_count workgroup holds 16 K records of 8 bytes, 8 K of 16)
-    // (k > 32: units of ~3.3 K records for the 512-thread count kernel, whose registers hold 4 K: 26.6 ms against 33.6 ms with
-    // units of 1.6 K and 45 ms with the 1024-thread kernel on the configs[4] batch)
-    const uint64_t split_above = WIDE ? 7000 : 14000, split_to = e->opt.cnt_split_to > 0 ? (uint64_t)e->opt.cnt_split_to : (WIDE ? 3400 : 6000);
-    if (st == DK_OK && s && unit_pieces == 1 && !list.extra && n_absent / p.n_seg > split_above) {
+    if (st == DK_OK && s && !sunk_fine && unit_pieces == 1 && !list.extra && n_absent / p.n_seg > split_above) {
         int bs = 1;
         while (bs < MAX_BIN_BITS && (n_absent >> (p.T + bs)) > split_to) bs++;
         const uint64_t n_fine = p.n_seg << bs;

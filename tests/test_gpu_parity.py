@@ -803,3 +803,28 @@ def test_many_absent_records_per_segment_are_split_before_counting(rng, k):
         assert_result_equals(res, km, cn)
         assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
         assert int(cn.max()) >= 2
+
+
+@pytest.mark.parametrize("k", [31, 45])
+def test_high_absent_rate_sinks_into_finer_units_while_probing(rng, k):
+    # 256 filter segments, ~4.5 M absent records (a child unrelated to its parents): the membership kernel samples the
+    # absent rate on the first segments and then appends the absent records straight to finer counting units, so the
+    # separate split of the absent lists (stage "count_split") is not needed; "sink_plain" brings it back.  Same results.
+    d = dk()
+    parents = random_reads(rng, 200, 150, 151)
+    child = random_reads(rng, 40000, 150, 151)
+    child = child + child[:3000] + parents[:50]
+    f, oist, km, cn, pst = oracle_trio(parents, child, k, 27, 4, 99)
+    got = {}
+    for plain in (0, 1):
+        with make_engine("bucketed", k=k, filter_log2_bits=27, n_hashes=4, seed=99) as eng:
+            eng.set_option("sink_plain", plain)
+            ks, ist, res = gpu_trio(eng, parents, child)
+            names = [n for n, _ in eng.timings()["stages"]]
+            assert ("count_split" in names) == bool(plain) and "overflow_redo" not in names, names
+            if not plain:
+                assert np.array_equal(ks.to_host(), f)
+            assert_result_equals(res, km, cn)
+            assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
+            got[plain] = res.stats["n_emitted"]
+    assert got[0] == got[1] and int(cn.max()) >= 2
