@@ -1199,9 +1199,10 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             }
         };
         auto have = [&](uint32_t c, int u) -> bool { return c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid < n; };
-        // bitmap of >= 8 bits per record (<= 12 % of the unique records collide), a power of two up to 64 Kbit
+        // bitmap of >= 16 bits per record where the geometry has them (<= 6 % of the unique records collide and take the
+        // table path), a power of two up to CNT_BM_WORDS
         uint32_t bm_words = 64;
-        while (bm_words * 4 < n && bm_words < (uint32_t)CNT_BM_WORDS) bm_words <<= 1;
+        while (bm_words * 2 < n && bm_words < (uint32_t)CNT_BM_WORDS) bm_words <<= 1;
         const uint32_t bm_mask = bm_words * 32 - 1;
         auto bit_of = [=](const R &rec, uint32_t &w, uint32_t &m) {
             const uint32_t b = (uint32_t)(fp_of(rec) >> 20) & bm_mask;

@@ -26,6 +26,13 @@ def short_name(kernel):
 LAST = 7      # the timed steps (and their warm-up) are the last launches of every kernel: bench.py --steps 5 --warmup 2
 
 
+def steady(ls, grid_of):
+    """the last LAST launches of a kernel's steady shape: of its final 3 * LAST launches, those with the grid of the larger
+    of the last two (a dk_probe step launches the membership kernel twice -- on 64 sampled segments, then on all)"""
+    top = max(int(grid_of(x) or 0) for x in ls[-2:])
+    return [x for x in ls[-3 * LAST:] if int(grid_of(x) or 0) == top][-LAST:]
+
+
 def trace_summary(src, dst):
     """per engine kernel: average duration of its last LAST launches (the child steps; the parent build, which runs the
     partition kernels on other shapes, comes first) and of all launches, from the kernel trace itself"""
@@ -40,7 +47,7 @@ def trace_summary(src, dst):
     rows = []
     for name, ls in sorted(by.items()):
         ls.sort()
-        last = ls[-LAST:]
+        last = steady(ls, lambda x: x[2])
         rows.append({"Kernel": name, "Calls": len(ls), "AverageNs_all": round(sum(x[1] for x in ls) / len(ls)),
                      "Last_launches": len(last), "AverageNs_last": round(sum(x[1] for x in last) / len(last)),
                      "Grid_Size_last": last[-1][2], "Workgroup_Size_last": last[-1][3]})
@@ -94,7 +101,7 @@ def main():
             out_rows.append({"Dispatch_Id": r["Dispatch_Id"], "Kernel": name, "Grid_Size": r["Grid_Size"],
                              "Workgroup_Size": r["Workgroup_Size"], "LDS_Block_Size": r["LDS_Block_Size"],
                              "VGPR_Count": r["VGPR_Count"], "Counter_Name": counter, "Counter_Value_KiB": r["Counter_Value"]})
-            per.setdefault(name, {}).setdefault(counter, []).append(float(r["Counter_Value"]))
+            per.setdefault(name, {}).setdefault(counter, []).append((int(r["Grid_Size"]), float(r["Counter_Value"])))
         with open(os.path.join(dst, f"pmc_{counter}.csv"), "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(out_rows[0].keys()))
             w.writeheader()
@@ -102,13 +109,15 @@ def main():
     cfg = (line or {}).get("config", {})
     traffic = {"note": "HBM bytes per launch from rocprofv3 PMC (separate --pmc passes, tools/profile_round.sh). FETCH_SIZE "
                        "and WRITE_SIZE are in KiB; FETCH_SIZE is doubled for wide coalesced streaming reads on gfx950 "
-                       "(MI355X_MICROARCH.md, HBM section). Every kernel is averaged over its last %d launches = the child "
-                       "steps (the parent inserts, which launch the partition kernels on other shapes, come first)." % LAST,
+                       "(MI355X_MICROARCH.md, HBM section). Every kernel is averaged over its last %d launches of full size = the child "
+                       "steps (the parent inserts, which launch the partition kernels on other shapes, come first; the sampling "
+                       "launch of the membership kernel on 64 segments is left out)." % LAST,
                "workload": cfg.get("name"), "reads": cfg.get("reads_per_sample"), "log2_bits": cfg.get("filter_log2_bits"), "kernels": {}}
     for name, c in per.items():
-        f, wv = c.get("FETCH_SIZE", [])[-LAST:], c.get("WRITE_SIZE", [])[-LAST:]
-        if not f or not wv:
+        if not c.get("FETCH_SIZE") or not c.get("WRITE_SIZE"):
             continue
+        f = [v for _, v in steady(c["FETCH_SIZE"], lambda x: x[0])]
+        wv = [v for _, v in steady(c["WRITE_SIZE"], lambda x: x[0])]
         fm, wm = sum(f) / len(f), sum(wv) / len(wv)
         traffic["kernels"][name] = {"fetch_bytes_corrected": fm * 1024 * 2, "write_bytes": wm * 1024,
                                     "hbm_bytes_per_launch": fm * 1024 * 2 + wm * 1024,
