@@ -140,6 +140,21 @@ __device__ __forceinline__ uint64_t rec_lo(const Rec2 &r, uint64_t seed) { retur
 __device__ __forceinline__ bool rec_eq(const Rec1 &a, const Rec1 &b) { return a.h == b.h; }
 __device__ __forceinline__ bool rec_eq(const Rec2 &a, const Rec2 &b) { return a.h == b.h && a.hi == b.hi; }
 
+// a store through a pointer that was kept as an integer (LDS-resident addresses): tell the compiler it is global memory,
+// or it emits a flat store, which also occupies the LDS counter the kernel's ds_* waits look at
+typedef unsigned long long dk_ull2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_global(Rec1 *dst, const Rec1 &r)
+{
+    *(__attribute__((address_space(1))) unsigned long long *)dst = r.h;
+}
+__device__ __forceinline__ void store_global(Rec2 *dst, const Rec2 &r)
+{
+    dk_ull2 v;
+    v.x = r.h;
+    v.y = r.hi;
+    *(__attribute__((address_space(1))) dk_ull2 *)dst = v;
+}
+
 template <class R>
 struct OvfList {
     R *recs;
@@ -223,12 +238,14 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     __shared__ SplitLds<THREADS, PER_THREAD, R> L;
     const int tid = (int)threadIdx.x;
     const int nbins = 1 << b1;
-    const int shift = 64 - b1 - (WINDOWED ? wbits : 0);
-    const int wshift = 64 - wbits;                       // WINDOWED only (wbits >= 1)
-    auto bin_of = [=](uint64_t h) -> uint32_t {
-        if constexpr (WINDOWED) return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1);
-        else return b1 ? (uint32_t)(h >> shift) : 0u;
-    };
+    // the bin and the window come from the top 32 bits of the hash (b1 + wbits <= 32): one v_bfe_u32 / one 32-bit shift
+    // instead of a 64-bit shift and a mask
+    const uint32_t bshift = (uint32_t)(32 - b1 - (WINDOWED ? wbits : 0));
+    const uint32_t wshift = (uint32_t)(32 - wbits);      // WINDOWED only (wbits >= 1)
+    uint32_t b1_v;                                       // the field width, kept in a vector register (one scalar operand per instruction)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(b1_v) : "s"((uint32_t)b1));
+    auto bin_of = [=](uint64_t h) -> uint32_t { return __builtin_amdgcn_ubfe((uint32_t)(h >> 32), bshift, b1_v); };
+    const uint64_t canon_mask = canonical ? ~0ULL : 0ULL;
     uint32_t n_records = 0, n_overflow = 0;
     uint32_t n_all = 0;                                   // WINDOWED: valid windows inside or outside the window
     multisplit_init(L, nbins);
@@ -273,6 +290,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             const uint32_t inside = left >= (uint64_t)PER_THREAD ? (1u << PER_THREAD) - 1u
                                                                  : ~((1u << (PER_THREAD - (uint32_t)left)) - 1u) & ((1u << PER_THREAD) - 1u);
             okbits = ~bad & inside;
+            if constexpr (WINDOWED) n_all += (uint32_t)__popc(okbits);
         }
     };
     // window j of the tile being hashed -> record; returns true when the window is a k-mer
@@ -280,12 +298,15 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         uint64_t kh = 0, kl;
         bool bad;
         if (!WIDE) {
-            const uint64_t win = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+            // 64 bits of the stream from base j on: two funnel shifts over (v0, top word of v1); j < 16
+            const uint32_t a2 = (uint32_t)(v0 >> 32), a1 = (uint32_t)v0, a0 = (uint32_t)(v1 >> 32);
+            const uint64_t win = j ? ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, 32 - 2 * j) << 32) | __builtin_amdgcn_alignbit(a1, a0, 32 - 2 * j) : v0;
             const uint64_t fwd = win >> sk;
             if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
             else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
             bad = false;                                   // decided for all windows at once in prep()
-            kl = (canonical && rcl < fwd) ? rcl : fwd;
+            // (the strand choice as a lane mask ANDed with the option on the scalar unit: one compare and one pair of selects)
+            kl = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(rcl < fwd) & canon_mask) ? rcl : fwd;
         } else {
             const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
             const uint64_t B = j ? (v1 << (2 * j)) | (v2 >> (64 - 2 * j)) : v1;
@@ -301,7 +322,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             }
             const uint64_t mx = j ? (mh << j) | (ml >> (64 - j)) : mh;
             bad = (mx >> kmask_shift) != 0;
-            const bool use_rc = canonical && (rch < fh || (rch == fh && rcl < fl));
+            const bool use_rc = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(rch < fh || (rch == fh && rcl < fl)) & canon_mask);
             kh = use_rc ? rch : fh;
             kl = use_rc ? rcl : fl;
         }
@@ -311,8 +332,8 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         if constexpr (!WIDE) ok = (okbits >> (PER_THREAD - 1 - j)) & 1u;
         else ok = !bad && p0 + j < s.n_bases;
         if constexpr (WINDOWED) {
-            n_all += ok;
-            ok = ok && (uint32_t)(rec.h >> wshift) == widx;
+            if constexpr (WIDE) n_all += ok;                // (k <= 32: counted per tile from okbits, in prep)
+            ok = ok && ((uint32_t)(rec.h >> 32) >> wshift) == widx;
         }
         return ok;
     };
@@ -410,7 +431,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                     rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
                 }
                 if (!checked) {
-                    if (mine) *dst = rec;
+                    if (mine) store_global(dst, rec);
                 } else {
                     if (mine && idx < capw) out[(uint64_t)bin * bin_stride + piece_base + idx] = rec;
                     ovf_append(ovf, mine && idx >= capw, rec, n_overflow);
