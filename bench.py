@@ -453,7 +453,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_child_only, n_absent_all, child_windows, gen_s = 0, 0, 0, 0.0
-        add_dev_ms, finish_dev_ms, finish_stage_ms = 0.0, 0.0, {}
+        add_dev_ms, finish_dev_ms, finish_stage_ms, finish_wall_s = 0.0, 0.0, {}, 0.0
         for w in range(R):
             acc.reset(w)
             for b in range(n_batches):
@@ -466,12 +466,15 @@ def main():
                 if w == 0:
                     child_windows += st["n_windows"]
                 cb.close()
+            tc = time.perf_counter()
             res = accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
             tf = eng.timings()
             finish_dev_ms += tf["total_ms"]
+            finish_wall_s += time.perf_counter() - tc
             for name, ms in tf["stages"]:
                 finish_stage_ms[name] = finish_stage_ms.get(name, 0.0) + ms
-            progress("end to end: pass %d of %d counted" % (w + 1, R))
+            progress("end to end: pass %d of %d counted (%.0f ms on the device, %.0f ms wall)"
+                     % (w + 1, R, tf["total_ms"], (time.perf_counter() - tc) * 1e3))
             n_child_only += len(res)
             n_absent_all += res.stats["n_absent"]
             res.close()
@@ -491,7 +494,7 @@ def main():
                "child_gkmers_s": child_windows / (child_seconds - gen_s) / 1e9,
                "hash_windows": R, "batches_per_pass": n_batches, "min_count": wl["min_count"],
                "device_seconds_adds": add_dev_ms * 1e-3, "device_seconds_counting": finish_dev_ms * 1e-3,
-               "counting_stages_ms": finish_stage_ms,
+               "counting_stages_ms": finish_stage_ms, "wall_seconds_counting": finish_wall_s,
                "absent_occurrences": n_absent_all, "child_only_kmers": n_child_only,
                "trio_seconds": parent_seconds + allreduce_ms * 1e-3 + child_seconds,
                "trio_gkmers_s": (parent_windows + child_windows) / (parent_seconds + allreduce_ms * 1e-3 + child_seconds) / 1e9,

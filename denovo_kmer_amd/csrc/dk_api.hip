@@ -411,7 +411,8 @@ static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, d
         }
     }
     if (st == DK_OK)
-        st = bucketed_count_stage<WIDE>(e, list, n_units, Tu, unit_base, n_records, n_aovf, min_count, res);
+        st = bucketed_count_stage<WIDE>(e, list, n_units, Tu, unit_base, n_records, n_aovf, min_count, res,
+                                        (uint64_t)(pieces ? n_pieces : 1u) * n_units * a->unit_cap);
     pool_free(e, extra);
     pool_free(e, idx);
     return st;
@@ -580,6 +581,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"repart_bits", &dk_options::repart_bits, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
+        {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},
         {"merge_idx64", &dk_options::merge_idx64, 0, 1},
     };
     for (const Opt &o : opts) {
@@ -1440,13 +1442,15 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
     // a unit that still runs full sends the rest to the overflow list, which is counted with it (exact either way)
     {
         const double mean = (double)capacity_records / (double)a->n_units;
-        // unit stride = a multiple of 4 KiB plus 128 bytes: the count kernel's workgroups read consecutive units at the same
-        // time, and strides that sit near a large power of two pile those reads onto few HBM channels (measured on the
-        // 9.6 x 10^9 records of a whole-genome pass: 66 ms at 12 304 records per unit, 150 ms at 11 758, 217 ms at 12 288).
+        // unit stride = a multiple of 4 KiB plus 128 bytes, i.e. never a power of two: the count kernel's workgroups read
+        // consecutive units at the same time, and with a stride of exactly 128 KiB all of those reads land on the same HBM
+        // channels -- 2966 ms instead of 55 for the 9.6 x 10^9 records of a whole-genome pass; every other stride tried
+        // (20..32 x 4 KiB + 128 B, 96 KiB exactly, odd sizes) takes the same 55 ms (tools/experiments/accum_count.py).
         // The smallest such capacity that leaves 5 sigma of room (the rare unit beyond it spills to the overflow list).
         const uint32_t rec_bytes = wide ? 16u : 8u, per_4k = 4096u / rec_bytes, odd = 128u / rec_bytes;
         const uint32_t need = (uint32_t)(mean + 5.0 * sqrt(mean + 1.0)) + 1u;
         a->unit_cap = (need > odd ? (need - odd + per_4k - 1) / per_4k * per_4k : 0u) + odd;
+        if ((uint32_t)e->opt.accum_unit_cap >= need) a->unit_cap = (uint32_t)e->opt.accum_unit_cap;
     }
     a->wide = wide;
     a->store = nullptr;

@@ -30,6 +30,7 @@ struct dk_options {
     int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
     int sub_split = 0;            // sub-segment split of the set kernels: 0 = automatic, 1..3 = force, 9 = never
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes
+    int accum_unit_cap = 0;       // dk_accum_create: records per counting unit, when at least what the capacity needs (test hook)
     int sink_plain = 0;           // dk_probe: never sink the absent records into finer counting units (test hook)
     int merge_idx64 = 0;          // dk_result_merge: 64-bit candidate indices whatever the size
 };

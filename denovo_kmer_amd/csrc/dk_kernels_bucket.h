@@ -1657,7 +1657,11 @@ acc_append_kmers_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restr
 inline uint32_t piece_capacity(double mean, double ratio)
 {
     const double c = mean + 8.0 * sqrt((mean + 1.0) * ratio) + 256.0;
-    return (uint32_t)((uint64_t)(c + 1.0) + 1) & ~1u;
+    uint32_t cap = (uint32_t)((uint64_t)(c + 1.0) + 1) & ~1u;
+    // never a stride that is a multiple of 16 KiB: regions read side by side at a large power-of-two stride share their HBM
+    // channels (a 128-KiB unit stride made seg_count 54 times slower, dk_accum_create)
+    if (cap % 2048 == 0) cap += 16;
+    return cap;
 }
 
 inline double segment_ratio(const dk_engine *e)
@@ -2016,7 +2020,7 @@ inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &
 template <bool WIDE>
 inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename RecOf<WIDE>::type> &list, uint64_t n_units,
                                       int Tc, uint64_t unit_base, uint64_t n_absent, uint64_t extra_room, uint32_t min_count,
-                                      dk_result *res)
+                                      dk_result *res, uint64_t size_records = 0)
 {
     if (!n_absent) return DK_OK;
     const uint64_t per_seg = n_absent / n_units;
@@ -2046,7 +2050,9 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
     // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
     // overflow records may all sit in one segment, hence the extra room for them
     const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, n_units);
-    const uint64_t bound = min_count > 1 ? n_absent / min_count / 8 : n_absent;
+    // size_records (accumulators: their capacity): the optimistic table is sized from it instead of from n_absent, so that
+    // every counting pass of one accumulator asks the pool for the same block and none of them waits for hipMalloc
+    const uint64_t bound = min_count > 1 ? std::max(n_absent, size_records) / min_count / 8 : n_absent;
     uint64_t region_cap = bound / used_regions + bound / (8 * used_regions) + 65536 + extra_room;
     dk_status st = DK_OK;
     for (int attempt = 0; attempt < 2; attempt++) {
