@@ -229,7 +229,7 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE, bool WINDOWED>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
                  typename RecOf<WIDE>::type *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles,
-                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx)
+                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx, uint32_t bin_skew)
 {
     using R = typename RecOf<WIDE>::type;
     constexpr int TILE = THREADS * PER_THREAD;
@@ -264,7 +264,9 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     const int sk = (WIDE ? 128 : 64) - 2 * k;            // right-alignment shift of a window
     const uint64_t kmask_shift = 64 - k;
     const uint64_t G = gridDim.x, w = blockIdx.x;
-    const uint64_t piece_base = w * capw, bin_stride = G * capw;
+    // bin_skew: records between the end of one bin's pieces and the start of the next bin's (keeps the 2^b1 write frontiers
+    // of a workgroup, G * capw records apart, off a common multiple of 4 KiB)
+    const uint64_t piece_base = w * capw, bin_stride = G * capw + bin_skew;
 
     // the tile being hashed: stream left-aligned at p0 -- bases in (v0, v1[, v2]), flags in (mh, ml)
     uint64_t p0 = 0, v0 = 0, v1 = 0, v2 = 0, mh = 0, ml = 0, rch = 0, rcl = 0;
@@ -584,7 +586,7 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES, class R>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
-              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0)
+              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0, uint32_t bin_skew = 0)
 {
     constexpr int TILE = THREADS * PER_THREAD;
     constexpr int NB = THREADS >= MAX_BINS2 ? MAX_BINS2 : MAX_BINS;      // the bin scan is one thread per bin
@@ -610,7 +612,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
     for (int i = tid; i < NB; i += THREADS) L.cnt[i] = 0;
     if (tid == 0) L.ovf_seen = 0;
-    const R *src = in + piece * capw;
+    const R *src = in + piece * capw + (uint64_t)b * bin_skew;
     R hs[PER_THREAD];
 #pragma unroll
     for (int j = 0; j < PER_THREAD; j++) {
@@ -1833,7 +1835,11 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 {
     using R = typename RecOf<WIDE>::type;
     const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
-    const uint64_t lvl1_recs = (uint64_t)p.p1 * p.G * p.capw;
+    // 128 bytes between the pieces of consecutive level-1 bins: a workgroup of scan_part writes to 2^b1 frontiers that are
+    // G * capw records apart, always a multiple of 4 KiB, so all of them sat on the same few HBM channels at any moment
+    // (configs[1]: scan_part 4.75 -> 4.35 ms with the skew)
+    const uint32_t l1_skew = 128u / (uint32_t)sizeof(R);
+    const uint64_t lvl1_recs = (uint64_t)p.p1 * (p.G * (uint64_t)p.capw + l1_skew);
     const uint64_t n_coarse = p.b3 ? 1ULL << (p.b1 + p.b2) : 0;
     const uint64_t coarse_recs = n_coarse * p.capA;
     // two levels: a = level-1 pieces (then the absent lists), b = segments.  three: a = level 1, then segments; b = coarse (then absent lists)
@@ -1865,14 +1871,14 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #define DK_SCAN_LAUNCH(TH, PT, W, WIN)                                                                                    \
     scan_part_kernel<TH, PT, W, WIDE, WIN><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical,           \
                                                                       e->cfg.seed, p.b1, p.capw, B.a, B.cnt1, n_tiles,    \
-                                                                      ovf, e->d_ctr, wbits, widx)
+                                                                      ovf, e->d_ctr, wbits, widx, l1_skew)
     // level 2: the level-1 pieces -> the segments' regions, or (three levels) -> 2^(b1+b2) coarse regions
 #define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
     do {                                                                                                  \
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<repart_grid(p.G * tpp, p.p1), TH, 0, e->stream>>>(                   \
             B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
-            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, !e->opt.repart_plain && p.p1 % 8 == 0);              \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, !e->opt.repart_plain && p.p1 % 8 == 0, l1_skew);     \
     } while (0)
     // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
 #define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \
