@@ -1837,7 +1837,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
     // 128 bytes between the pieces of consecutive level-1 bins: a workgroup of scan_part writes to 2^b1 frontiers that are
     // G * capw records apart, always a multiple of 4 KiB, so all of them sat on the same few HBM channels at any moment
-    // (configs[1]: scan_part 4.75 -> 4.35 ms with the skew)
+    // (configs[1]: scan_part 4.75 -> 4.35 ms on one box, no difference on others)
     const uint32_t l1_skew = 128u / (uint32_t)sizeof(R);
     const uint64_t lvl1_recs = (uint64_t)p.p1 * (p.G * (uint64_t)p.capw + l1_skew);
     const uint64_t n_coarse = p.b3 ? 1ULL << (p.b1 + p.b2) : 0;

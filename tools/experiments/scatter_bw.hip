@@ -37,11 +37,13 @@ int main()
     hipEventCreate(&a);
     hipEventCreate(&b);
     const uint32_t runs[] = {8192, 256, 128, 64, 32, 16, 8};
-    for (uint32_t nbins : {128u, 256u, 32768u}) {
+    for (uint32_t nbins : {64u, 256u, 1024u}) {
         for (uint32_t run : runs) {
             if (8192 / run < 1) continue;
             const uint64_t runs_per_tile_bin = (8192 / run + nbins - 1) / nbins;
-            const uint64_t region_stride = (uint64_t)n_tiles * runs_per_tile_bin * run;
+            // skew: the regions' strides are otherwise multiples of 8 MiB, and all write frontiers advance in step
+            for (uint32_t skew : {0u, 16u, 48u}) {
+            const uint64_t region_stride = (uint64_t)n_tiles * runs_per_tile_bin * run + skew;
             if (region_stride * nbins > (n + (64ULL << 20)) * 2) continue;
             float best = 1e9f, best_w = 1e9f;
             for (int it = 0; it < 3; it++) {
@@ -59,8 +61,9 @@ int main()
                 hipEventElapsedTime(&ms, a, b);
                 if (ms < best_w) best_w = ms;
             }
-            printf("nbins %6u run %5u records (%6u B): %.2f ms  %.2f TB/s (read+write)   write only: %.2f ms  %.2f TB/s\n", nbins, run,
-                   run * 8, best, 2.0 * n * 8 / best / 1e9, best_w, 1.0 * n * 8 / best_w / 1e9);
+            printf("nbins %6u run %5u records (%6u B) skew %3u B: %.2f ms  %.2f TB/s (read+write)   write only: %.2f ms  %.2f TB/s\n", nbins, run,
+                   run * 8, skew * 8, best, 2.0 * n * 8 / best / 1e9, best_w, 1.0 * n * 8 / best_w / 1e9);
+            }
         }
     }
     return 0;
