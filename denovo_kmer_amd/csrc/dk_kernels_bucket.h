@@ -2166,6 +2166,10 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
                         stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
                         st = sync_counters(e, "bucketed probe");
                         if (st == DK_ERR_OVERFLOW) {
+                            pool_free(e, B.fine_cursor);        // (the fallback below may allocate them again)
+                            pool_free(e, B.fine);
+                            B.fine_cursor = nullptr;
+                            B.fine = nullptr;
                             e->h_ctr->n_overflow = 0;
                             e->h_ctr->n_absent = 0;
                             h = hipMemsetAsync(&e->d_ctr->n_overflow, 0, 8, e->stream);

@@ -131,7 +131,8 @@ dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
  *   test hooks, which force a kernel geometry on inputs too small to select it:
  *   "scan_variant" 1..6, "repart_variant" 0..1, "force_l3" 0..1, "b1_up" -4..4, "count_seg" >= 64, "cnt_mid" >= 1,
  *   "sub_split" 0..3 | 9 (0 = automatic, 9 = never), "repart_plain" 0..1, "merge_pass_bits" 0..8, "merge_idx64" 0..1,
- *   "sink_plain" 0..1 (1: dk_probe never routes absent records into finer counting units while probing) */
+ *   "sink_plain" 0..1 (1: dk_probe never routes absent records into finer counting units while probing),
+ *   "accum_unit_cap" records per counting unit of the next dk_accum_create, used when it is at least what the capacity needs */
 dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
 /* The engine keeps the device memory of finished operations in a pool for the next one (no allocation inside timed
  * work); it hands cached blocks back by itself when an allocation fails.  dk_engine_trim frees every cached block now --

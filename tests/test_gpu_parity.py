@@ -828,3 +828,23 @@ def test_high_absent_rate_sinks_into_finer_units_while_probing(rng, k):
             assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
             got[plain] = res.stats["n_emitted"]
     assert got[0] == got[1] and int(cn.max()) >= 2
+
+
+def test_sunk_unit_running_full_falls_back_to_the_plain_probe(rng):
+    # as above, plus one read 4000 times over: its 120 k-mers (absent from the parents) each add 4000 records to one of the
+    # finer units, more than the unit has room for -- the membership kernel reports the overflow and the batch is probed
+    # again the plain way (whole-segment absent lists, split before counting where they fit); results equal the oracle's
+    d = dk()
+    k = 31
+    parents = random_reads(rng, 200, 150, 151)
+    child = random_reads(rng, 40000, 150, 151)
+    heavy = random_reads(rng, 1, 150, 151)
+    child = child + heavy * 4000 + parents[:50]
+    f, oist, km, cn, pst = oracle_trio(parents, child, k, 27, 4, 5)
+    with make_engine("bucketed", k=k, filter_log2_bits=27, n_hashes=4, seed=5) as eng:
+        ks, ist, res = gpu_trio(eng, parents, child)
+        names = [n for n, _ in eng.timings()["stages"]]
+        assert names.count("seg_probe") == 2 and "overflow_redo" not in names, names
+        assert_result_equals(res, km, cn)
+        assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
+        assert int(cn.max()) >= 4000
