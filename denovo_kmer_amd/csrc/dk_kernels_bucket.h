@@ -478,6 +478,7 @@ kmers_tile_kernel(StreamView s, int k, int canonical, uint64_t seed, uint64_t *_
     const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
     const int sk = (WIDE ? 128 : 64) - 2 * k;
     const uint64_t kmask_shift = 64 - k;
+    const uint64_t canon_mask = canonical ? ~0ULL : 0ULL;
     uint64_t n_valid = 0;
 #pragma unroll 1
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -503,12 +504,13 @@ kmers_tile_kernel(StreamView s, int k, int canonical, uint64_t seed, uint64_t *_
             uint64_t kh = 0, kl;
             bool bad;
             if (!WIDE) {
-                const uint64_t win = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
+                const uint32_t a2 = (uint32_t)(v0 >> 32), a1 = (uint32_t)v0, a0 = (uint32_t)(v1 >> 32);      // (as in scan_part)
+                const uint64_t win = j ? ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, 32 - 2 * j) << 32) | __builtin_amdgcn_alignbit(a1, a0, 32 - 2 * j) : v0;
                 const uint64_t fwd = win >> sk;
                 if (j == 0) rcl = (~rev_pairs64(fwd)) >> sk;
                 else rcl = (rcl >> 2) | ((uint64_t)(3u - (uint32_t)(fwd & 3)) << (2 * k - 2));
                 bad = ((mh << j) >> kmask_shift) != 0;
-                kl = (canonical && rcl < fwd) ? rcl : fwd;
+                kl = __builtin_amdgcn_inverse_ballot_w64(__builtin_amdgcn_ballot_w64(rcl < fwd) & canon_mask) ? rcl : fwd;
             } else {
                 const uint64_t A = j ? (v0 << (2 * j)) | (v1 >> (64 - 2 * j)) : v0;
                 const uint64_t B = j ? (v1 << (2 * j)) | (v2 >> (64 - 2 * j)) : v1;
