@@ -219,3 +219,55 @@ def test_native_allreduce_world_one_through_the_abi():
             with pytest.raises(d.DkError):
                 eng.comm_init(None, 1, 1)
             ks.close()
+
+
+def test_rccl_collectives_on_library_memory_with_one_rank():
+    """The multi-GPU exchange hands torch.distributed (backend nccl = RCCL) tensors that wrap the LIBRARY's device memory
+    (dist._device_bytes over __cuda_array_interface__: the accumulator's store and fill counters), not memory of torch's
+    allocator.  One rank is all a single GPU allows, but it runs the same calls on the same kind of tensor: all_to_all_single,
+    all_reduce and all_gather_into_tensor must take the wrapped memory and leave what the library put there."""
+    import torch
+    import torch.distributed as dist
+    import denovo_kmer_amd as d
+    from denovo_kmer_amd.dist import _device_bytes
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    rng = np.random.default_rng(11)
+    reads = ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(3000)]
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        with d.Engine(k=31, filter_log2_bits=24, seed=5, mode="bucketed") as eng:
+            dev = torch.device("cuda", eng.device_id)
+            acc = d.ChildAccumulator(eng, None, capacity_records=1 << 20, window_index=0, window_count=1)
+            acc.add(d.ReadBatch.from_sequences(eng, reads))
+            n_units, cap, rb = acc.geometry()
+            sp, fp, op, n_ovf = acc.device_view()
+            store = _device_bytes(sp, n_units * cap * rb, dev).view(1, n_units * cap * rb)
+            fill = _device_bytes(fp, n_units * 4, dev).view(torch.int32).view(1, n_units)
+            assert int(fill.sum().item()) + n_ovf == acc.stats()["n_absent"] > 300000
+            recv_store, recv_fill = torch.empty_like(store), torch.empty_like(fill)
+            dist.all_to_all_single(recv_fill, fill)
+            dist.all_to_all_single(recv_store, store)
+            gathered = torch.empty(n_units, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(gathered, fill.view(-1))
+            total = fill.sum().to(torch.int64).view(1)
+            dist.all_reduce(total)
+            torch.cuda.synchronize()
+            assert torch.equal(recv_fill, fill) and torch.equal(recv_store, store) and torch.equal(gathered, fill.view(-1))
+            assert int(total.item()) == int(fill.sum().item())
+            # counting from the received copy gives what counting in place gives
+            ref = acc.finish(min_count=1)
+            got = acc.finish_pieces(recv_store.data_ptr(), recv_fill.data_ptr(), 1, 0, n_units, 0, 0, 1,
+                                    keepalive=(recv_store, recv_fill))
+            (ahi, alo, acnt), (bhi, blo, bcnt) = ref.to_host(), got.to_host()          # sorted by k-mer
+            assert len(alo) == len(blo) > 0
+            assert np.array_equal(alo, blo) and np.array_equal(acnt, bcnt)
+            ref.close()
+            got.close()
+            acc.close()
+    finally:
+        dist.destroy_process_group()
