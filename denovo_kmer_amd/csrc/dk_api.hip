@@ -1260,7 +1260,7 @@ dk_status dk_comm_init(dk_engine *e, const uint8_t *id, uint32_t rank, uint32_t 
     c->world = world_size;
     c->staging = nullptr;
     c->staging_bytes = 0;
-    if (world_size > 1) {
+    if (world_size > 1 || id != nullptr) {       // (one rank WITH an id: a real communicator of one, see set_allreduce)
         RcclApi *api = rccl();
         if (!api->lib) { delete c; return fail(e, DK_ERR_UNSUPPORTED, "%s", api->err.c_str()); }
         ncclUniqueId_t u;
@@ -1294,7 +1294,7 @@ dk_status dk_set_allreduce_or(dk_set *s, uint64_t *bytes_sent)
     dk_engine *e = s->e;
     DK_HIP(e, hipSetDevice(e->device));
     DK_TRY(dk::set_allreduce(e, s, bytes_sent));
-    if (e->comm && e->comm->world > 1 && e->h_ctr->n_set_full) return set_full(e);
+    if (e->comm && e->comm->comm && e->h_ctr->n_set_full) return set_full(e);
     return DK_OK;
 }
 

@@ -90,14 +90,19 @@ inline dk_status set_allreduce(dk_engine *e, dk_set *s, uint64_t *bytes_sent)
 {
     dk_comm *c = e->comm;
     if (bytes_sent) *bytes_sent = 0;
-    if (!c || c->world == 1) return DK_OK;
+    if (!c || !c->comm) return DK_OK;           // no communicator, or one rank without RCCL
     RcclApi *api = rccl();
     const uint64_t P = c->world, r = c->rank;
+    // A communicator of ONE rank (dk_comm_init with an id and world_size 1) runs every call below with the rank as its own
+    // peer: its slice goes through ncclSend / ncclRecv into the staging buffer and is combined with itself (x | x = x, a
+    // table united with itself), then the in-place all-gather -- the whole path on a single GPU, results unchanged.
+    const bool own_peer = P == 1;
+    const uint64_t n_peers = own_peer ? 1 : P - 1;
     if (s->n_bytes % (P * SEG_BYTES) != 0)
         return fail(e, DK_ERR_UNSUPPORTED, "the set (%llu bytes) does not split into whole 64-KiB segments over %llu ranks",
                     (unsigned long long)s->n_bytes, (unsigned long long)P);
     const uint64_t sl = s->n_bytes / P;
-    uint64_t piece = c->staging_bytes / (P - 1) / SEG_BYTES * SEG_BYTES;
+    uint64_t piece = c->staging_bytes / n_peers / SEG_BYTES * SEG_BYTES;
     if (piece > sl) piece = sl;
     if (piece == 0) return fail(e, DK_ERR_INVALID_ARG, "staging buffer below 64 KiB per peer");
     char *base = (char *)s->d_words;
@@ -108,10 +113,10 @@ inline dk_status set_allreduce(dk_engine *e, dk_set *s, uint64_t *bytes_sent)
         const uint64_t nb = std::min(piece, sl - off);
         DK_RCCL(e, api->GroupStart());
         for (uint64_t q = 0; q < P; q++) {
-            if (q == r) continue;
+            if (q == r && !own_peer) continue;
             // piece of slice q goes to rank q; the same piece of my slice comes from rank q
             DK_RCCL(e, api->Send(base + q * sl + off, nb, RCCL_UINT8, (int)q, c->comm, e->stream));
-            DK_RCCL(e, api->Recv((char *)c->staging + (q < r ? q : q - 1) * nb, nb, RCCL_UINT8, (int)q, c->comm, e->stream));
+            DK_RCCL(e, api->Recv((char *)c->staging + (own_peer ? 0 : q < r ? q : q - 1) * nb, nb, RCCL_UINT8, (int)q, c->comm, e->stream));
         }
         DK_RCCL(e, api->GroupEnd());
         char *dst = base + r * sl + off;
@@ -119,13 +124,13 @@ inline dk_status set_allreduce(dk_engine *e, dk_set *s, uint64_t *bytes_sent)
             const uint64_t first_seg = (r * sl + off) / SEG_BYTES, n_seg = nb / SEG_BYTES;
             if (e->cfg.k > 32)
                 union_slices_kernel<true><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
-                    (unsigned long long *)dst, (const unsigned long long *)c->staging, P - 1, nb / 8, first_seg, T, e->d_ctr);
+                    (unsigned long long *)dst, (const unsigned long long *)c->staging, n_peers, nb / 8, first_seg, T, e->d_ctr);
             else
                 union_slices_kernel<false><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
-                    (unsigned long long *)dst, (const unsigned long long *)c->staging, P - 1, nb / 8, first_seg, T, e->d_ctr);
+                    (unsigned long long *)dst, (const unsigned long long *)c->staging, n_peers, nb / 8, first_seg, T, e->d_ctr);
         } else {
             or_slices_kernel<<<grid_for(e, nb / 16, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                (uint4 *)dst, (const uint4 *)c->staging, P - 1, nb / 16);
+                (uint4 *)dst, (const uint4 *)c->staging, n_peers, nb / 16);
         }
         h = hipGetLastError();
         if (h != hipSuccess) return fail(e, DK_ERR_HIP, "slice reduction failed: %s", hipGetErrorString(h));

@@ -204,8 +204,11 @@ void      dk_set_destroy(dk_set *s);
  * library composes it on the engine's stream: all-to-all of slices (ncclSend/ncclRecv) -> local OR / union kernel ->
  * ncclAllGather, in pieces that bound the staging memory (1 GiB).  librccl.so.1 is loaded on first use.
  *   dk_comm_unique_id  one rank creates the id; the host hands the 128 bytes to the other ranks (MPI, TCP, a file)
- *   dk_comm_init       collective over all ranks: joins the engine to the communicator (one per engine)
- *   dk_set_allreduce_or  collective; a no-op with world_size 1 or without a communicator; bytes_sent may be NULL */
+ *   dk_comm_init       collective over all ranks: joins the engine to the communicator (one per engine).  world_size 1
+ *                      with id NULL needs no RCCL at all; world_size 1 WITH an id makes a real communicator of one rank
+ *   dk_set_allreduce_or  collective; a no-op without a communicator (or with the RCCL-less one-rank kind); a one-rank
+ *                      RCCL communicator runs the whole composition with the rank as its own peer -- the set is
+ *                      unchanged (x | x = x) -- which lets a single GPU exercise the path.  bytes_sent may be NULL */
 #define DK_COMM_ID_BYTES 128
 dk_status dk_comm_unique_id(uint8_t *id /* DK_COMM_ID_BYTES */);
 dk_status dk_comm_init(dk_engine *e, const uint8_t *id /* DK_COMM_ID_BYTES */, uint32_t rank, uint32_t world_size);

@@ -271,3 +271,27 @@ def test_rccl_collectives_on_library_memory_with_one_rank():
             acc.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("set_kind,bits", [("bloom", 26), ("exact", 26)])
+def test_native_rccl_allreduce_with_one_rank_as_its_own_peer(set_kind, bits):
+    """A one-rank RCCL communicator (dk_comm_unique_id + dk_comm_init(id, 0, 1)) sends the rank's slice to itself through
+    ncclSend / ncclRecv, combines it with itself in the OR / union kernel and all-gathers in place: every RCCL entry point
+    the library loads runs on the engine's stream, and the set must come out unchanged.  The staging buffer is 1 GiB, the
+    set 8 MiB, so this is one piece; two GPUs and more are the driver's run."""
+    import denovo_kmer_amd as d
+    rng = np.random.default_rng(4)
+    reads = ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(2000)]
+    with d.Engine(k=31, filter_log2_bits=bits, seed=9, set_kind=set_kind) as eng:
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(reads)
+        before = ks.to_host()
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        assert ks.allreduce_or() == 0                  # nothing leaves the GPU
+        assert np.array_equal(ks.to_host(), before)
+        child = d.ReadBatch.from_sequences(eng, reads[:50] + ["".join(rng.choice(list("ACGT"), size=150)) for _ in range(50)])
+        res = d.KmerCounter(eng).child_only(child, ks)
+        assert res.stats["n_absent"] == 50 * 120       # the 50 parent reads are all found, the 50 new ones are not
+        res.close()
+        eng.comm_finalize()
+        ks.close()
