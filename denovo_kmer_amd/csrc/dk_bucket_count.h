@@ -1,0 +1,326 @@
+// dk_bucket_count.h -- seg_count: exact counting of the absent records of one counting unit
+// (part of the bucketed kernel family: dk_kernels_bucket.h has the overview and includes the parts in order)
+#pragma once
+#include "dk_bucket_seg.h"
+
+namespace dk {
+
+// Exact counting of one segment's absent records.
+// Most absent k-mers are singletons (sequencing errors), so a hash table for all of them is wasted
+// work.  Two 64-Kbit LDS bitmaps classify the records first: bit(h) set twice => the record MAY have
+// a twin (true duplicate or bitmap collision) and goes through a small LDS hash table; every other
+// record is provably unique and is emitted with count 1 straight from registers.  Exact for any
+// input: all copies of a k-mer share a bit, so all of them are flagged.
+// Two geometries: <512 threads, 2048 slots, 64-Kbit bitmaps> for segments with thousands of absent
+// records, <128, 512, 8 Kbit> (8 KB of LDS, many workgroups per CU) when a segment holds a few hundred.
+template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE>
+__global__ void __launch_bounds__(CNT_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
+seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
+                 uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
+                 uint32_t *__restrict__ out_cnt, Counters *ctr, uint64_t unit_base)
+{
+    // unit_base: the units counted are unit_base .. unit_base + n_seg of the 2^T hash-prefix ranges (a window of
+    // an accumulator).  Entries beyond a region's capacity are not written but still tallied in region_fill (and
+    // flagged through n_overflow), so a table sized too small tells how large it has to be.
+    // Every barrier of this kernel orders LDS traffic only (lds_barrier): records are read-only, results write-only, and
+    // a __syncthreads() would make every unit wait until the result stores of the previous phase have left the CU.
+    using R = typename RecOf<WIDE>::type;
+    constexpr int CNT_RPT = (WIDE && CNT_THREADS < 1024) ? 8 : 16;   // records held per thread (the 1024-thread geometry runs one workgroup per CU: 128 VGPRs)
+    constexpr int CNT_CHUNK = CNT_THREADS * CNT_RPT;
+    // k <= 32: the table key is the record's hash (EMPTY = a value outside this segment's prefix).
+    // k > 32: the key is a 64-bit fingerprint of (h, hi) (EMPTY = 0); the slot's owner stores (h, hi)
+    // beside it and every record re-checks the full key after the insert phase, so a fingerprint
+    // collision is detected (and the batch redone exactly) instead of merging two k-mers.
+    __shared__ unsigned long long keys[CNT_SLOTS];
+    __shared__ unsigned long long key_h[WIDE ? CNT_SLOTS : 1], key_hi[WIDE ? CNT_SLOTS : 1];
+    __shared__ uint32_t cnts[CNT_SLOTS];
+    __shared__ uint32_t bm_a[CNT_BM_WORDS], bm_b[CNT_BM_WORDS];
+    __shared__ uint32_t wave_sums[CNT_THREADS / 64];
+    __shared__ uint32_t total;
+    __shared__ unsigned long long gbase;
+    constexpr bool GATHER = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no registers to spare)
+    constexpr uint32_t WB = WIDE ? 32 : 64;              // per wave: flagged records gathered for one dense trip through the table
+    __shared__ R wbuf[GATHER ? CNT_THREADS / 64 : 1][WB];
+    const int tid = (int)threadIdx.x;
+    const int wave = tid >> 6;
+    uint32_t n_distinct = 0, n_fail = 0;
+    // this workgroup appends to output region `region` through that region's own fill counter
+    const uint32_t region = blockIdx.x % RESULT_REGIONS;
+    unsigned long long *fill = &ctr->region_fill[region];
+    const uint64_t region_base = (uint64_t)region * region_cap;
+    auto fp_of = [](const R &rec) -> unsigned long long {
+        if constexpr (WIDE) {
+            const unsigned long long f = fmix64(rec.h ^ (rec_hi(rec) * 0x9E3779B97F4A7C15ULL));
+            return f ? f : 1ULL;
+        } else {
+            return rec.h;
+        }
+    };
+    // persistent: a workgroup walks segments blockIdx.x, +gridDim.x, ... (launching one tiny
+    // workgroup per segment cost ~50 ns of wall time each at 2^18 segments)
+    for (uint64_t seg_id = blockIdx.x; seg_id < n_seg; seg_id += gridDim.x) {
+        const SegPieces<R> sp = seg_pieces(pl, seg_id);
+        const uint32_t n = sp.total();
+        if (n == 0) continue;
+        const unsigned long long EMPTY = WIDE ? 0ULL : (unsigned long long)((seg_id + unit_base) ^ 1ULL) << (64 - T);
+        const uint32_t n_chunks = (n + CNT_CHUNK - 1) / CNT_CHUNK;
+        const bool single = n_chunks == 1;                 // the common case: the records stay in registers
+        R hv[CNT_RPT];
+        auto load_chunk = [&](uint32_t c) {
+#pragma unroll
+            for (int u = 0; u < CNT_RPT; u++) {
+                const uint32_t i = c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid;
+                hv[u] = sp.at(i < n ? i : 0);
+            }
+        };
+        auto have = [&](uint32_t c, int u) -> bool { return c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid < n; };
+        // bitmap of >= 16 bits per record where the geometry has them (<= 6 % of the unique records collide and take the
+        // table path), a power of two up to CNT_BM_WORDS
+        uint32_t bm_words = 64;
+        while (bm_words * 2 < n && bm_words < (uint32_t)CNT_BM_WORDS) bm_words <<= 1;
+        const uint32_t bm_mask = bm_words * 32 - 1;
+        auto bit_of = [=](const R &rec, uint32_t &w, uint32_t &m) {
+            const uint32_t b = (uint32_t)(fp_of(rec) >> 20) & bm_mask;
+            w = b >> 5;
+            m = 1u << (b & 31);
+        };
+        // k > 32: the bitmap position of a record costs an fmix64; with the records in registers (single) it is
+        // computed once and kept, like the verdict of pass 2 (fbits) that passes 3 and 4 would otherwise re-derive
+        constexpr bool KEEP_BITS = WIDE && CNT_RPT == 8;
+        uint32_t bidx[KEEP_BITS ? CNT_RPT : 1];
+        uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
+        for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
+        if (single) load_chunk(0);
+        lds_barrier();
+        // pass 1: mark
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            if (!single) load_chunk(c);
+#pragma unroll
+            for (int u = 0; u < CNT_RPT; u++) {
+                if (!have(c, u)) continue;
+                uint32_t w, m;
+                bit_of(hv[u], w, m);
+                if constexpr (KEEP_BITS) bidx[u] = (w << 5) | (uint32_t)__builtin_ctz(m);
+                if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
+            }
+        }
+        lds_barrier();
+        // pass 2: classify; per-wave count of provably unique records, block count of flagged ones
+        uint32_t my_unique = 0, my_flagged = 0;
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            if (!single) load_chunk(c);
+#pragma unroll
+            for (int u = 0; u < CNT_RPT; u++) {
+                if (!have(c, u)) continue;
+                uint32_t w, m;
+                if (KEEP_BITS && single) { w = bidx[u] >> 5; m = 1u << (bidx[u] & 31); }
+                else bit_of(hv[u], w, m);
+                const bool fl = (bm_b[w] & m) != 0;
+                if (fl) my_flagged++; else my_unique++;
+                if constexpr (KEEP_BITS) fbits |= (fl ? 1u : 0u) << u;
+            }
+        }
+        auto flagged = [&](int u, const R &rec) -> bool {
+            if constexpr (KEEP_BITS) {
+                if (single) return (fbits >> u) & 1u;
+            }
+            uint32_t w, m;
+            bit_of(rec, w, m);
+            return (bm_b[w] & m) != 0;
+        };
+        const uint32_t emit_unique = min_count <= 1 ? 1u : 0u;
+        const uint32_t wave_unique = wave_total(my_unique);          // uniform per wave
+        (void)block_excl_scan<true>(my_flagged, wave_sums, &total);
+        const uint32_t n_flagged = total;
+        lds_barrier();
+        // bases of the waves' unique runs: prefix over the per-wave totals
+        if ((tid & 63) == 0) wave_sums[wave] = wave_unique;
+        lds_barrier();
+        uint32_t wave_base = 0, all_unique = 0;
+#pragma unroll
+        for (int v = 0; v < CNT_THREADS / 64; v++) {
+            const uint32_t x = wave_sums[v];
+            if (v < wave) wave_base += x;
+            all_unique += x;
+        }
+        n_distinct += (tid == 0) ? all_unique : 0;
+        if (tid == 0) gbase = (emit_unique && all_unique) ? atomicAdd(fill, (unsigned long long)all_unique) : 0ULL;
+        lds_barrier();
+        // pass 3: emit the unique records, each wave a contiguous run, compacted by ballot
+        if (emit_unique && all_unique) {
+            uint64_t o = gbase + wave_base;
+            for (uint32_t c = 0; c < n_chunks; c++) {
+                if (!single) load_chunk(c);
+#pragma unroll
+                for (int u = 0; u < CNT_RPT; u++) {
+                    const bool uniq = have(c, u) && !flagged(u, hv[u]);
+                    const uint64_t bal = __ballot(uniq);
+                    if (uniq) {
+                        const uint64_t pos = o + (uint64_t)popc_below(bal);
+                        if (pos < region_cap) {
+                            out_kmer[region_base + pos] = rec_lo(hv[u], seed);
+                            if constexpr (WIDE) out_hi[region_base + pos] = rec_hi(hv[u]);
+                            out_cnt[region_base + pos] = 1;
+                        } else {
+                            n_fail++;               // region full: host redoes the batch with the direct family
+                        }
+                    }
+                    o += (uint64_t)__popcll(bal);
+                }
+            }
+        }
+        // Flagged records: exact counts in the LDS hash table, one sub-range of the key space per
+        // round.  The number of rounds starts from a guess (8 copies per key) and a round whose keys
+        // do not fit is split in four and redone -- nothing of it has been emitted yet -- so a segment
+        // holding a million copies of one k-mer costs one round, not a thousand.
+        if (n_flagged) {
+            uint32_t slots = 256;
+            while (slots < 2 * n_flagged && slots < (uint32_t)CNT_SLOTS) slots <<= 1;
+            const uint32_t slot_mask = slots - 1;
+            uint32_t rounds = (n_flagged + 4 * slots - 1) / (4 * slots);
+            uint32_t r = 0;
+            while (r < rounds) {
+                lds_barrier();
+                for (uint32_t i = tid; i < slots; i += CNT_THREADS) { keys[i] = EMPTY; cnts[i] = 0; }
+                if (tid == 0) total = 0;                       // doubles as the "round does not fit" flag
+                lds_barrier();
+                for (int phase = 0; phase < (WIDE ? 2 : 1); phase++) {
+                    // phase 0: insert and count.  phase 1 (k > 32): re-check the full key of every record
+                    if (GATHER && single) {
+                        // Records in registers.  Flagged records are few per register slot (~10 % of the lanes when nearly every
+                        // k-mer is unique), and a trip through the table is a chain of LDS round trips: going slot by slot
+                        // cost eight (sixteen) chains per wave with a handful of lanes each -- half of the kernel's time.  The
+                        // wave gathers its flagged records in a 64-entry LDS buffer instead and walks the table with all
+                        // lanes busy, once per 64 records.
+                        R *const wb = wbuf[GATHER ? wave : 0];
+                        auto walk = [&](uint32_t cnt) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t lane = (uint32_t)lane_id();
+                            bool active = lane < cnt;
+                            const R cur = wb[lane & (WB - 1)];
+                            const unsigned long long f = fp_of(cur);
+                            uint32_t slot = (uint32_t)(f >> 8) & slot_mask, tries = 0;
+                            while (__any(active)) {
+                                if (active) {
+                                    if (phase == 0) {
+                                        const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, f);
+                                        if (prev == EMPTY) {
+                                            if constexpr (WIDE) { key_h[slot] = cur.h; key_hi[slot] = rec_hi(cur); }
+                                        }
+                                        if (prev == EMPTY || prev == f) {
+                                            atomicAdd(&cnts[slot], 1u);
+                                            active = false;
+                                        } else {
+                                            slot = (slot + 1) & slot_mask;
+                                            if (++tries == 64) { total = 1; active = false; }      // too crowded: split this round
+                                        }
+                                    } else {
+                                        if (keys[slot] == f) {
+                                            if (key_h[slot] != cur.h || key_hi[slot] != rec_hi(cur)) n_fail++;
+                                            active = false;
+                                        } else {
+                                            slot = (slot + 1) & slot_mask;
+                                            if (++tries == 64) { n_fail++; active = false; }
+                                        }
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        };
+                        uint32_t held = 0;                                 // records in the wave's buffer (wave-uniform)
+#pragma unroll
+                        for (int u = 0; u < CNT_RPT; u++) {
+                            bool want = have(0, u) && flagged(u, hv[u]);
+                            if (want && rounds > 1) {
+                                const unsigned long long fu = fp_of(hv[u]);
+                                want = (uint32_t)((((fu >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20) == r;
+                            }
+#pragma unroll
+                            for (uint32_t part = 0; part < 64 / WB; part++) {          // at most WB records join at a time
+                                const bool mine = want && (WB == 64 || (uint32_t)lane_id() / WB == part);
+                                const uint64_t m = __ballot(mine);
+                                const uint32_t c = (uint32_t)__popcll(m);
+                                if (c == 0) continue;
+                                if (held + c > WB) { walk(held); held = 0; }
+                                if (mine) wb[held + (uint32_t)popc_below(m)] = hv[u];
+                                held += c;
+                            }
+                        }
+                        if (held) walk(held);
+                    } else
+                    for (uint32_t c = 0; c < n_chunks; c++) {
+                        if (!single) load_chunk(c);
+#pragma unroll
+                        for (int u = 0; u < CNT_RPT; u++) {
+                            if (!have(c, u)) continue;
+                            const R rec = hv[u];
+                            if (!flagged(u, rec)) continue;
+                            const unsigned long long f = fp_of(rec);
+                            const uint32_t rr = (uint32_t)((((f >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20);
+                            if (rr != r) continue;
+                            uint32_t slot = (uint32_t)(f >> 8) & slot_mask;
+                            uint32_t tries = 0;
+                            if (phase == 0) {
+                                for (; tries < 64; tries++) {
+                                    const unsigned long long prev = atomicCAS(&keys[slot], EMPTY, f);
+                                    if (prev == EMPTY) {
+                                        if constexpr (WIDE) { key_h[slot] = rec.h; key_hi[slot] = rec_hi(rec); }
+                                    }
+                                    if (prev == EMPTY || prev == f) { atomicAdd(&cnts[slot], 1u); break; }
+                                    slot = (slot + 1) & slot_mask;
+                                }
+                                if (tries == 64) total = 1;        // too crowded: split this round
+                            } else {
+                                for (; tries < 64 && keys[slot] != f; tries++) slot = (slot + 1) & slot_mask;
+                                if (tries == 64 || key_h[slot] != rec.h || key_hi[slot] != rec_hi(rec)) n_fail++;
+                            }
+                        }
+                    }
+                    lds_barrier();
+                    if (total) break;
+                }
+                if (total) {
+                    if (rounds >= (1u << 18)) { n_fail++; r = rounds; break; }   // cannot split further: redo on the direct family
+                    rounds *= 4;
+                    r *= 4;
+                    continue;
+                }
+                uint32_t mine = 0;
+                for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS)
+                    if (keys[sl] != EMPTY) { n_distinct++; if (cnts[sl] >= min_count) mine++; }
+                const uint32_t ex = block_excl_scan<true>(mine, wave_sums, &total);
+                if (tid == 0) gbase = total ? atomicAdd(fill, (unsigned long long)total) : 0ULL;
+                lds_barrier();
+                uint64_t o = gbase + ex;
+                for (uint32_t sl = tid; sl < slots; sl += CNT_THREADS) {
+                    if (keys[sl] != EMPTY && cnts[sl] >= min_count) {
+                        if (o < region_cap) {
+                            if constexpr (WIDE) {
+                                const Rec2 kr{key_h[sl], key_hi[sl]};
+                                out_kmer[region_base + o] = rec_lo(kr, seed);
+                                out_hi[region_base + o] = kr.hi;
+                            } else {
+                                out_kmer[region_base + o] = unfmix64(keys[sl]) ^ seed;
+                            }
+                            out_cnt[region_base + o] = cnts[sl];
+                        } else {
+                            n_fail++;
+                        }
+                        o++;
+                    }
+                }
+                r++;
+            }
+        }
+        lds_barrier();
+    }
+    n_distinct = (uint32_t)wave_sum(n_distinct);
+    n_fail = (uint32_t)wave_sum(n_fail);
+    if (lane_id() == 0) {
+        if (n_distinct) atomicAdd(&ctr->n_distinct, (unsigned long long)n_distinct);
+        if (n_fail) atomicAdd(&ctr->n_overflow, (unsigned long long)n_fail);
+    }
+}
+
+}  // namespace dk
