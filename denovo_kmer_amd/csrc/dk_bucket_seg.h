@@ -286,9 +286,15 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     constexpr int UNROLL = 8;                 // records in flight per thread: loads first, then the LDS tests
     R rec[UNROLL];
     bool have[UNROLL];
+    // A wave whose slot u lies beyond the segment's records skips the slot altogether (and every later one): with 3.7 K
+    // records per segment -- a whole-genome batch against 2^19 segments -- more than half of the 8192 slots of an iteration
+    // are empty, and the tests of an empty slot cost what those of a record cost.
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x);
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
+            have[u] = false;
+            if (i0 + (uint32_t)u * SEG_THREADS + wave_first >= n) break;
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
             rec[u] = sp.at(have[u] ? i : 0);
@@ -302,6 +308,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     for (uint32_t i0 = 0;;) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
+            if (i0 + (uint32_t)u * SEG_THREADS + wave_first >= n) break;
             const uint64_t hu = rec[u].h;
             const uint32_t blk = (uint32_t)(hu >> blk_shift) & (SEG_BLOCKS - 1);
             const uint32_t a = (uint32_t)(hu & 511), d = (uint32_t)((hu >> 9) & 511) | 1u;
