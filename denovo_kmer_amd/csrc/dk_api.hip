@@ -79,7 +79,7 @@ void stage_begin(dk_engine *e)
 
 void stage_mark(dk_engine *e, const char *name)
 {
-    if (e->n_ev >= DK_MAX_STAGES) return;
+    if (e->n_ev >= DK_MAX_MARKS) return;
     snprintf(e->ev_name[e->n_ev], sizeof e->ev_name[0], "%s", name);
     e->n_ev++;
     (void)hipEventRecord(e->ev[e->n_ev], e->stream);
@@ -90,12 +90,18 @@ dk_status stage_end(dk_engine *e)
     DK_HIP(e, hipStreamSynchronize(e->stream));
     dk_timings &t = e->timings;
     memset(&t, 0, sizeof t);
-    t.n_stages = (uint32_t)e->n_ev;
+    // marks of the same name (the slabs of a slab-wise operation) are summed into one stage, in order of first appearance
     for (int i = 0; i < e->n_ev; i++) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
-        t.stage_ms[i] = ms;
-        memcpy(t.stage_name[i], e->ev_name[i], sizeof t.stage_name[i]);
+        uint32_t j = 0;
+        while (j < t.n_stages && strncmp(t.stage_name[j], e->ev_name[i], sizeof t.stage_name[j]) != 0) j++;
+        if (j == t.n_stages) {
+            if (t.n_stages == DK_MAX_STAGES) continue;
+            memcpy(t.stage_name[j], e->ev_name[i], sizeof t.stage_name[j]);
+            t.n_stages++;
+        }
+        t.stage_ms[j] += ms;
     }
     if (e->n_ev) (void)hipEventElapsedTime(&t.total_ms, e->ev[0], e->ev[e->n_ev]);
 #ifdef DK_STAMPS
@@ -307,8 +313,9 @@ static dk_status merge_results(dk_engine *e, const dk_result *const *results, ui
 
 // the exact redo path of dk_accum_add (and the small-batch path): the direct family lists the absent k-mers of the
 // batch, which are hashed and appended to their units through global cursors
+// h_from: only k-mers whose hash is >= h_from (what a slab-wise bucketed pass had not completed when its partition failed)
 template <bool WIDE>
-static dk_status accum_add_direct(dk_engine *e, dk_accum *a, const dk_reads *r)
+static dk_status accum_add_direct(dk_engine *e, dk_accum *a, const dk_reads *r, uint64_t h_from = 0)
 {
     using R = typename RecOf<WIDE>::type;
     const StreamView sv = view_of(r);
@@ -333,8 +340,12 @@ static dk_status accum_add_direct(dk_engine *e, dk_accum *a, const dk_reads *r)
                   (unsigned long long)e->h_ctr->n_cand, (unsigned long long)cand_cap);
     if (st == DK_OK && h == hipSuccess && e->h_ctr->n_cand) {
         const uint64_t n = e->h_ctr->n_cand;
-        acc_append_kmers_kernel<WIDE><<<grid_for(e, n, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-            cand_lo, cand_hi, n, e->cfg.seed, a->wbits, a->widx, accum_unit_bits(a), accum_unit_base(a), accum_out<R>(e, a), e->d_ctr);
+        if (a->packed && !WIDE)
+            acc_append_kmers_kernel<WIDE, !WIDE><<<grid_for(e, n, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                cand_lo, cand_hi, n, e->cfg.seed, a->wbits, a->widx, accum_unit_bits(a), accum_unit_base(a), accum_out<R>(e, a), e->d_ctr, h_from);
+        else
+            acc_append_kmers_kernel<WIDE, false><<<grid_for(e, n, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                cand_lo, cand_hi, n, e->cfg.seed, a->wbits, a->widx, accum_unit_bits(a), accum_unit_base(a), accum_out<R>(e, a), e->d_ctr, h_from);
         h = hipGetLastError();
         if (h == hipSuccess) stage_mark(e, "acc_append");
     }
@@ -412,7 +423,7 @@ static dk_status accum_finish_t(dk_engine *e, dk_accum *a, uint32_t min_count, d
     }
     if (st == DK_OK)
         st = bucketed_count_stage<WIDE>(e, list, n_units, Tu, unit_base, n_records, n_aovf, min_count, res,
-                                        (uint64_t)(pieces ? n_pieces : 1u) * n_units * a->unit_cap);
+                                        (uint64_t)(pieces ? n_pieces : 1u) * n_units * a->unit_cap, a->packed);
     pool_free(e, extra);
     pool_free(e, idx);
     return st;
@@ -579,6 +590,12 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"sub_split", &dk_options::sub_split, 0, 9},
         {"repart_plain", &dk_options::repart_plain, 0, 1},
         {"repart_bits", &dk_options::repart_bits, 0, 10},
+        {"scan_bits", &dk_options::scan_bits, 0, 10},
+        {"slabs", &dk_options::slabs, 0, 1024},
+        {"slab_mb", &dk_options::slab_mb, 0, 1 << 20},
+        {"ovf_cap", &dk_options::ovf_cap, 0, 1 << 30},
+        {"accum_plain", &dk_options::accum_plain, 0, 1},
+        {"accum_min_u", &dk_options::accum_min_u, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},
@@ -1388,8 +1405,6 @@ static dk_result *result_new(dk_engine *e)
     return res;
 }
 
-static size_t accum_rec_bytes(const dk_accum *a) { return a->wide ? sizeof(Rec2) : sizeof(Rec1); }
-
 static dk_status accum_clear(dk_accum *a)
 {
     dk_engine *e = a->e;
@@ -1423,7 +1438,7 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
     // counting units: 2^u per segment, so that a unit's records fit the registers of one seg_count workgroup
     const uint64_t n_seg_w = 1ULL << (T - wbits);
     const uint64_t unit_target = wide ? 6144 : 12288;
-    int u = 0;
+    int u = std::min(e->opt.accum_min_u, MAX_SUB_BITS);
     while (u < MAX_SUB_BITS && capacity_records / (n_seg_w << u) > unit_target) u++;
     if (capacity_records / (n_seg_w << u) > unit_target)
         return fail(e, DK_ERR_UNSUPPORTED, "capacity %llu is more than %llu records per hash window of this set geometry: use more windows",
@@ -1438,8 +1453,13 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
     a->T = T;
     a->u = u;
     a->n_units = n_seg_w << u;
+    a->wide = wide;
+    // packed unit records (6 bytes): whenever the unit's hash prefix covers at least 16 bits, i.e. the remaining 48 fit
+    a->packed = !wide && !e->opt.accum_plain && T + u >= PACKED_MIN_PREFIX_BITS;
     // room per unit = mean + 5 sigma of a Poisson fill: absent occurrences are sequencing errors, i.e. independent;
-    // a unit that still runs full sends the rest to the overflow list, which is counted with it (exact either way)
+    // a unit that still runs full sends the rest to the overflow list, which is counted with it (exact either way).
+    // Without a set (KmerCounter over batches) every copy of a k-mer lands in one unit: the variance is then the mean times
+    // the multiplicity (piece_capacity's ratio), so sigma is scaled by the same segment_ratio the partition uses.
     {
         const double mean = (double)capacity_records / (double)a->n_units;
         // unit stride = a multiple of 4 KiB plus 128 bytes, i.e. never a power of two: the count kernel's workgroups read
@@ -1447,21 +1467,29 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
         // channels -- 2966 ms instead of 55 for the 9.6 x 10^9 records of a whole-genome pass; every other stride tried
         // (20..32 x 4 KiB + 128 B, 96 KiB exactly, odd sizes) takes the same 55 ms (tools/experiments/accum_count.py).
         // The smallest such capacity that leaves 5 sigma of room (the rare unit beyond it spills to the overflow list).
-        const uint32_t rec_bytes = wide ? 16u : 8u, per_4k = 4096u / rec_bytes, odd = 128u / rec_bytes;
-        const uint32_t need = (uint32_t)(mean + 5.0 * sqrt(mean + 1.0)) + 1u;
-        a->unit_cap = (need > odd ? (need - odd + per_4k - 1) / per_4k * per_4k : 0u) + odd;
+        // Packed units (6-byte records): a multiple of 64 records (both arrays of the unit stay 128-byte aligned) whose
+        // stride in bytes is not a multiple of 16 KiB.
+        const double sig = s ? 1.0 : sqrt(segment_ratio(e));
+        const uint32_t need = (uint32_t)(mean + 5.0 * sig * sqrt(mean + 1.0)) + 1u;
+        if (a->packed) {
+            a->unit_cap = (need + 63) / 64 * 64;
+            if (((uint64_t)a->unit_cap * PACKED_REC_BYTES) % 16384 == 0) a->unit_cap += 64;
+        } else {
+            const uint32_t rec_bytes = wide ? 16u : 8u, per_4k = 4096u / rec_bytes, odd = 128u / rec_bytes;
+            a->unit_cap = (need > odd ? (need - odd + per_4k - 1) / per_4k * per_4k : 0u) + odd;
+        }
         if ((uint32_t)e->opt.accum_unit_cap >= need) a->unit_cap = (uint32_t)e->opt.accum_unit_cap;
+        if (a->packed) a->unit_cap = (a->unit_cap + 1) & ~1u;           // (a forced capacity: the u16 array stays 4-byte aligned)
     }
-    a->wide = wide;
     a->store = nullptr;
     a->fill = nullptr;
     a->ovf = nullptr;
     a->d_novf = nullptr;
     a->ovf_cap = std::max<uint64_t>(1ULL << 16, capacity_records / 64);
-    const size_t rb = accum_rec_bytes(a);
+    const size_t rb = accum_rec_bytes(a), ovf_rb = wide ? sizeof(Rec2) : sizeof(Rec1);    // (the overflow list holds plain records)
     dk_status st = pool_alloc(e, a->n_units * (uint64_t)a->unit_cap * rb, &a->store);
     if (st == DK_OK) st = pool_alloc(e, a->n_units * 4, (void **)&a->fill);
-    if (st == DK_OK) st = pool_alloc(e, a->ovf_cap * rb, &a->ovf);
+    if (st == DK_OK) st = pool_alloc(e, a->ovf_cap * ovf_rb, &a->ovf);
     if (st == DK_OK) st = pool_alloc(e, 256, (void **)&a->d_novf);
     if (st == DK_OK) st = accum_clear(a);
     if (st != DK_OK) { dk_accum_destroy(a); return st; }
@@ -1504,8 +1532,8 @@ dk_status dk_accum_stats(const dk_accum *a, dk_stats *out)
 dk_status dk_accum_device_bytes(const dk_accum *a, uint64_t *n_bytes)
 {
     if (!a || !n_bytes) return DK_ERR_INVALID_ARG;
-    const size_t rb = a->wide ? sizeof(Rec2) : sizeof(Rec1);
-    *n_bytes = a->n_units * (uint64_t)a->unit_cap * rb + a->n_units * 4 + a->ovf_cap * rb + 256;
+    const size_t rb = accum_rec_bytes(a), ovf_rb = a->wide ? sizeof(Rec2) : sizeof(Rec1);
+    *n_bytes = a->n_units * (uint64_t)a->unit_cap * rb + a->n_units * 4 + a->ovf_cap * ovf_rb + 256;
     return DK_OK;
 }
 
@@ -1523,28 +1551,32 @@ dk_status dk_accum_add(dk_accum *a, const dk_reads *r, dk_stats *stats)
     if (r->n_bases) {
         bool direct = e->cfg.mode == DK_MODE_DIRECT ||
                       (e->cfg.mode == DK_MODE_AUTO && (a->s ? !dk::bucketed_pays(e, r->n_bases, a->wbits) : r->n_bases < (1ULL << 22)));
+        uint64_t redo_from = 0, absent_done = 0;
         if (!direct) {
-            bool appended = false;
-            st = e->cfg.k > 32 ? dk::bucketed_accum_add_t<true>(e, a, r, &appended) : dk::bucketed_accum_add_t<false>(e, a, r, &appended);
-            if (st == DK_ERR_OVERFLOW && !appended) {
-                // the partition lost records before anything was appended: redo the batch exactly
+            bool fatal = false;
+            st = e->cfg.k > 32 ? dk::bucketed_accum_add_t<true>(e, a, r, &fatal, &redo_from, &absent_done)
+                               : dk::bucketed_accum_add_t<false>(e, a, r, &fatal, &redo_from, &absent_done);
+            if (st == DK_ERR_OVERFLOW && !fatal) {
+                // the partition lost records: what it had not completed (hashes >= redo_from) is redone exactly
                 hipError_t h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
                 st = h == hipSuccess ? DK_OK : fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h));
                 memset(e->h_ctr, 0, sizeof(Counters));
                 stage_mark(e, "overflow_redo");
                 direct = true;
-            } else if (st != DK_OK && appended) {
+            } else if (st != DK_OK && fatal) {
                 a->failed = true;
             }
         }
         if (direct && st == DK_OK) {
-            st = e->cfg.k > 32 ? accum_add_direct<true>(e, a, r) : accum_add_direct<false>(e, a, r);
+            st = e->cfg.k > 32 ? accum_add_direct<true>(e, a, r, redo_from) : accum_add_direct<false>(e, a, r, redo_from);
             if (st != DK_OK) a->failed = true;
+            else e->h_ctr->n_absent += absent_done;
         }
     }
     if (st == DK_ERR_OVERFLOW && a->failed)
         st = fail(e, DK_ERR_OVERFLOW, "accumulator full: %llu occurrences found neither room in their unit nor in the overflow list "
-                  "(capacity too small for this sample: use more windows or a larger capacity)", (unsigned long long)e->h_ctr->n_overflow);
+                  "(capacity too small for this sample: use more windows or a larger capacity)",
+                  (unsigned long long)(e->h_ctr->n_sink_drop + e->h_ctr->n_overflow));
     if (st == DK_OK) st = stage_end(e);
     if (st != DK_OK) return st;
     a->n_batches++;
@@ -1601,7 +1633,7 @@ dk_status dk_accum_geometry(const dk_accum *a, uint64_t *n_units, uint32_t *unit
     if (!a) return DK_ERR_INVALID_ARG;
     if (n_units) *n_units = a->n_units;
     if (unit_cap) *unit_cap = a->unit_cap;
-    if (record_bytes) *record_bytes = (uint32_t)(a->wide ? sizeof(Rec2) : sizeof(Rec1));
+    if (record_bytes) *record_bytes = (uint32_t)accum_rec_bytes(a);
     return DK_OK;
 }
 

@@ -15,8 +15,9 @@ constexpr int SEG_BYTES = SEG_BLOCKS * 64;
 constexpr int PART_THREADS = 1024;
 constexpr int PART_PER_THREAD = 8;
 constexpr int PART_TILE = PART_THREADS * PART_PER_THREAD;   // positions (or records) per tile
-constexpr int MAX_BIN_BITS = 9;                        // level 1 (scan_part: private pieces, the runs must stay long)
+constexpr int MAX_BIN_BITS = 9;                        // 512-thread multisplit kernels (the bin scan is one thread per bin): k > 32, small geometries
 constexpr int MAX_BINS = 1 << MAX_BIN_BITS;
+constexpr int MAX_BIN_BITS1 = 10;                      // level 1 of the 1024-thread scan_part (16 K-record tiles: runs of 16 records)
 constexpr int MAX_BIN_BITS2 = 10;                      // later levels (repart: one bin per XCD, its L2 assembles the lines of short runs)
 constexpr int MAX_BINS2 = 1 << MAX_BIN_BITS2;
 constexpr int MAX_SEG_BITS = 23;                       // two levels up to 18 bits, three levels beyond (coarse regions <= 2^15: grid y)
@@ -51,6 +52,11 @@ struct BucketPlan {
     int tile;              // positions per scan_part tile
     int variant;           // scan_part geometry (see make_plan)
     int sbits;             // sub-segment split: every partition region covers 2^sbits 64-KiB segments (PieceList::sbits)
+    // Slab-wise level 2 (insert / accumulate, two levels): the scan writes all level-1 bins once; the bins are then taken
+    // `slab_bins` at a time -- repart of the slab's bins into ONE slab-sized set of regions, the set kernel over the slab's
+    // segments, next slab -- so the regions need 1 / slabs of the room (2^39 bits, 32 M reads: 40 GB -> 0.6-5 GB), which is
+    // what lets a whole-genome child pass run in ONE hash window beside the filter and a full-size accumulator.
+    uint32_t slabs, slab_bins;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
@@ -165,8 +171,9 @@ __device__ __forceinline__ void ovf_append(const OvfList<R> &ovf, bool pred, con
 // out as per-bin runs.  Three barriers per tile (A: counts done - by the caller, B: offsets ready,
 // C: stage ready); the next tile's count phase needs no barrier because it touches only cnt[],
 // which wave 0 re-zeroes before B.
-template <int THREADS, int PER_THREAD, class R, int NB = MAX_BINS, bool PRIVATE = true>
+template <int THREADS, int PER_THREAD, class R, int NB = (THREADS >= 1024 ? 1024 : MAX_BINS), bool PRIVATE = true>
 struct SplitLds {
+    static constexpr int N_BINS = NB;
     R stage[THREADS * PER_THREAD];
     uint32_t cnt[NB];           // per-tile counts; zero on entry to every count phase
     uint32_t off[NB];           // tile offset of each bin in stage[]
@@ -181,7 +188,7 @@ struct SplitLds {
 template <int THREADS, int PER_THREAD, class R>
 __device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD, R> &L, int nbins)
 {
-    for (int i = (int)threadIdx.x; i < MAX_BINS; i += THREADS) { L.cnt[i] = 0; L.cur[i] = 0; }
+    for (int i = (int)threadIdx.x; i < L.N_BINS; i += THREADS) { L.cnt[i] = 0; L.cur[i] = 0; }
     if (threadIdx.x == 0) L.ovf_seen = 0;
     __syncthreads();
 }

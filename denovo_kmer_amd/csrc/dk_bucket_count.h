@@ -13,7 +13,9 @@ namespace dk {
 // input: all copies of a k-mer share a bit, so all of them are flagged.
 // Two geometries: <512 threads, 2048 slots, 64-Kbit bitmaps> for segments with thousands of absent
 // records, <128, 512, 8 Kbit> (8 KB of LDS, many workgroups per CU) when a segment holds a few hundred.
-template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE>
+// PACKED (k <= 32 only): the pieces are units of an accumulator's packed store (6 bytes per record, dk_bucket_seg.h); the
+// extra list (the accumulator's overflow records) holds plain records.
+template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE, bool PACKED = false>
 __global__ void __launch_bounds__(CNT_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
                  uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
@@ -66,11 +68,27 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         const uint32_t n_chunks = (n + CNT_CHUNK - 1) / CNT_CHUNK;
         const bool single = n_chunks == 1;                 // the common case: the records stay in registers
         R hv[CNT_RPT];
+        const uint64_t prefix = (seg_id + unit_base) << (64 - T);      // PACKED: the hash bits every record of the unit shares
+        auto rec_at = [&](uint32_t i) -> R {
+            if constexpr (PACKED && !WIDE) {
+                if (i >= sp.start[MAX_R]) return sp.extra[i - sp.start[MAX_R]];
+                uint32_t r = 0, st = 0;
+                if (!sp.single) {
+#pragma unroll
+                    for (int q = 1; q < MAX_R; q++)
+                        if (i >= sp.start[q]) { r = (uint32_t)q; st = sp.start[q]; }
+                }
+                const uint64_t unit = pl.n_segs ? (uint64_t)r * pl.n_segs + seg_id : seg_id * pl.n_pieces + r;
+                return R{packed_load(pl.recs, unit, pl.piece_cap, i - st, prefix)};
+            } else {
+                return sp.at(i);
+            }
+        };
         auto load_chunk = [&](uint32_t c) {
 #pragma unroll
             for (int u = 0; u < CNT_RPT; u++) {
                 const uint32_t i = c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid;
-                hv[u] = sp.at(i < n ? i : 0);
+                hv[u] = rec_at(i < n ? i : 0);
             }
         };
         auto have = [&](uint32_t c, int u) -> bool { return c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid < n; };

@@ -58,6 +58,11 @@ inline int count_segments_log2(const dk_engine *e, uint64_t n_records)
 
 inline int set_segment_bits(const dk_engine *e) { return (int)e->cfg.filter_log2_bits - 9 - SEG_LOG2_BLOCKS; }
 
+// most hash bits a multisplit level may take: level 1 (scan_part, 1024 threads: 10; option "scan_bits" = 9 restores round 2's
+// limit for A/B runs) and later levels (repart: 10, option "repart_bits"); k > 32 runs 512-thread kernels: 9 each
+inline int level1_bits(const dk_engine *e) { return e->cfg.k > 32 ? MAX_BIN_BITS : (e->opt.scan_bits > 0 ? e->opt.scan_bits : MAX_BIN_BITS1); }
+inline int level2_bits(const dk_engine *e) { return e->cfg.k > 32 ? MAX_BIN_BITS : (e->opt.repart_bits > 0 ? e->opt.repart_bits : MAX_BIN_BITS2); }
+
 // Sub-segment split: with 2^19 segments to route to (a 2^38-bit set, or one of two hash windows of a 2^39-bit one) two
 // multisplit levels reach 2^18 regions and the segment kernels take the last bit, which saves the third pass over
 // the records (16 bytes per record of HBM traffic) for one re-read of a region by the workgroup of the sibling
@@ -69,8 +74,7 @@ inline int pick_sub_bits(const dk_engine *e, int T_local)
     if (o >= 1 && o <= 3) return T_local - o >= 1 ? o : 0;
     // (one bit only: four workgroups re-reading a region cost seg_insert more than the third pass -- 50.7 vs 34.8 + 19.7 ms
     // per 48 M reads at 2^39 bits)
-    const bool wide = e->cfg.k > 32;
-    const int two = MAX_BIN_BITS + (wide ? MAX_BIN_BITS : (e->opt.repart_bits > 0 ? e->opt.repart_bits : MAX_BIN_BITS2));
+    const int two = level1_bits(e) + level2_bits(e);
     return T_local == two + 1 ? 1 : 0;
 }
 
@@ -78,23 +82,25 @@ inline int pick_sub_bits(const dk_engine *e, int T_local)
 // hash window (1 / 2^wbits of them) are partitioned, over the T - wbits segment bits below the window's.
 // sbits > 0 (insert / accumulate against a set): the partition stops sbits bits short of the 64-KiB segments, the segment
 // kernels resolve them (PieceList::sbits); p->T, n_seg, cap2 then describe the regions.
-inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0, int wbits = 0, int sbits = 0)
+inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int T_override = 0, int wbits = 0, int sbits = 0,
+                      bool allow_slabs = false)
 {
     const bool wide = e->cfg.k > 32;
     p->sbits = sbits;
+    p->slabs = 1;
     p->T = (T_override > 0 ? T_override : set_segment_bits(e)) - wbits - sbits;
     if (p->T < 1 || p->T > MAX_SEG_BITS) return false;
     p->b3 = 0;
     p->capA = 0;
-    const int bits2 = wide ? MAX_BIN_BITS : (e->opt.repart_bits > 0 ? e->opt.repart_bits : MAX_BIN_BITS2);   // k > 32: 512-thread repart
-    if (p->T > MAX_BIN_BITS + bits2 || (e->opt.force_l3 && p->T >= 3)) {
+    const int bits1 = level1_bits(e), bits2 = level2_bits(e);
+    if (p->T > bits1 + bits2 || (e->opt.force_l3 && p->T >= 3)) {
         // three levels: thirds of T; the coarse regions (b1 + b2 bits) index the grid's y dimension
         p->b1 = p->T / 3;
         p->b2 = (p->T - p->b1) / 2;
         p->b3 = p->T - p->b1 - p->b2;
     } else {
         p->b1 = (p->T + e->opt.b1_up) / 2;
-        if (p->b1 > MAX_BIN_BITS) p->b1 = MAX_BIN_BITS;
+        if (p->b1 > bits1) p->b1 = bits1;
         if (p->T - p->b1 > bits2) p->b1 = p->T - bits2;
         p->b2 = p->T - p->b1;
     }
@@ -140,6 +146,21 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     // tile of neighbouring pieces at the same time, and strides near a large power of two pile those reads
     // onto few HBM channels (measured 2 % on the whole pass)
     p->capw = (p->capw + 511) / 512 * 512 + 16;
+    // slabs: a power of two, at least 8 level-1 bins each (one per XCD for repart); automatic = the fewest that keep one
+    // slab's regions within the budget (option "slab_mb")
+    if (allow_slabs && !p->b3 && p->p1 >= 16) {
+        const uint32_t max_slabs = p->p1 / 8;
+        uint32_t S = 1;
+        if (e->opt.slabs > 0) {
+            while (S * 2 <= (uint32_t)e->opt.slabs && S * 2 <= max_slabs) S *= 2;
+        } else {
+            const uint64_t budget = (uint64_t)(e->opt.slab_mb > 0 ? e->opt.slab_mb : 1024) << 20;
+            const uint64_t rec_bytes = wide ? 16 : 8;
+            while (S < max_slabs && p->n_seg * (uint64_t)p->cap2 * rec_bytes / S > budget) S *= 2;
+        }
+        p->slabs = S;
+    }
+    p->slab_bins = p->p1 / p->slabs;
     return true;
 }
 
@@ -187,16 +208,41 @@ inline void free_bufs(dk_engine *e, BucketBufs<R> &B)
     B = BucketBufs<R>();
 }
 
+// level 2 of one slab (p.slabs == 1: of the whole batch): the level-1 pieces of the slab's bins -> the regions of these
+// bins in B.b (two levels), or -> 2^(b1+b2) coarse regions (three levels; never slab-wise)
+template <bool WIDE>
+inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename RecOf<WIDE>::type> &B, int wbits, uint32_t slab)
+{
+    using R = typename RecOf<WIDE>::type;
+    const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
+    const uint32_t l1_skew = 128u / (uint32_t)sizeof(R);
+    const uint32_t bin0 = slab * p.slab_bins;
+    const int affine = !e->opt.repart_plain && p.slab_bins % 8 == 0;
+#define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
+    do {                                                                                                  \
+        const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
+        repart_kernel<TH, PT, W, R><<<repart_grid(p.G * tpp, p.slab_bins), TH, 0, e->stream>>>(            \
+            B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \
+    } while (0)
+    if constexpr (WIDE) DK_REPART_LAUNCH(512, 8, 8);
+    else if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
+    else DK_REPART_LAUNCH(1024, 8, 8);
+#undef DK_REPART_LAUNCH
+}
+
 // scan_part + repart (+ repart): afterwards B.rec / B.cursor2 hold every record of the batch (of the hash window
 // widx of 2^wbits, when wbits > 0) grouped by segment, except the records that did not fit, which are in B.ovf
 // (Counters::n_ovf of them).  need_scratch: a second segment-sized buffer for the absent lists (per-batch probe).
+// Slab-wise plans (p.slabs > 1): only scan_part runs here and B.b is sized for ONE slab; the caller walks the slabs
+// (launch_repart + its set kernel, see slab_piece_list).
 template <bool WIDE>
 inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const BucketPlan &p,
                                     BucketBufs<typename RecOf<WIDE>::type> &B, int wbits = 0, uint32_t widx = 0,
                                     bool need_scratch = true)
 {
     using R = typename RecOf<WIDE>::type;
-    const uint64_t seg_recs = p.n_seg * (uint64_t)p.cap2;
+    const uint64_t seg_recs = p.n_seg / p.slabs * (uint64_t)p.cap2;
     // 128 bytes between the pieces of consecutive level-1 bins: a workgroup of scan_part writes to 2^b1 frontiers that are
     // G * capw records apart, always a multiple of 4 KiB, so all of them sat on the same few HBM channels at any moment
     // (configs[1]: scan_part 4.75 -> 4.35 ms on one box, no difference on others)
@@ -218,7 +264,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     B.rec = p.b3 ? B.a : B.b;
     B.scratch = p.b3 ? B.b : B.a;
     if (n_coarse) DK_HIP(e, hipMemsetAsync(B.cursorA, 0, n_coarse * 4, e->stream));
-    B.ovf_cap = std::max<uint64_t>(1ULL << 20, p.n_max / 8);
+    B.ovf_cap = e->opt.ovf_cap > 0 ? (uint64_t)e->opt.ovf_cap : std::max<uint64_t>(1ULL << 20, p.n_max / 8);
     DK_TRY(pool_alloc(e, B.ovf_cap * sizeof(R), (void **)&B.ovf));
     DK_HIP(e, hipMemsetAsync(B.cursor2, 0, p.n_seg * 4, e->stream));
     const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
@@ -234,14 +280,6 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     scan_part_kernel<TH, PT, W, WIDE, WIN><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical,           \
                                                                       e->cfg.seed, p.b1, p.capw, B.a, B.cnt1, n_tiles,    \
                                                                       ovf, e->d_ctr, wbits, widx, l1_skew)
-    // level 2: the level-1 pieces -> the segments' regions, or (three levels) -> 2^(b1+b2) coarse regions
-#define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
-    do {                                                                                                  \
-        const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
-        repart_kernel<TH, PT, W, R><<<repart_grid(p.G * tpp, p.p1), TH, 0, e->stream>>>(                   \
-            B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
-            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, !e->opt.repart_plain && p.p1 % 8 == 0, l1_skew);     \
-    } while (0)
     // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
 #define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \
     do {                                                                                                  \
@@ -253,14 +291,6 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     if constexpr (WIDE) {
         if (wbits) DK_SCAN_LAUNCH(512, 8, 4, true);
         else DK_SCAN_LAUNCH(512, 8, 4, false);
-        DK_HIP(e, hipGetLastError());
-        stage_mark(e, "scan_part");
-        DK_REPART_LAUNCH(512, 8, 8);
-        if (p.b3) {
-            DK_HIP(e, hipGetLastError());
-            stage_mark(e, "repart");
-            DK_REPART3_LAUNCH(512, 8, 8);
-        }
     } else {
         if (wbits) {
             if (p.variant == 6) DK_SCAN_LAUNCH(1024, 16, 4, true);
@@ -276,22 +306,30 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
             default: DK_SCAN_LAUNCH(1024, 8, 8, false); break;
             }
         }
+    }
+    DK_HIP(e, hipGetLastError());
+    stage_mark(e, "scan_part");
+    if (p.slabs > 1) return DK_OK;                          // the caller walks the slabs
+    launch_repart<WIDE>(e, p, B, wbits, 0);
+    if (p.b3) {
         DK_HIP(e, hipGetLastError());
-        stage_mark(e, "scan_part");
-        if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
-        else DK_REPART_LAUNCH(1024, 8, 8);
-        if (p.b3) {
-            DK_HIP(e, hipGetLastError());
-            stage_mark(e, "repart");
-            DK_REPART3_LAUNCH(1024, 8, 8);
-        }
+        stage_mark(e, "repart");
+        if constexpr (WIDE) DK_REPART3_LAUNCH(512, 8, 8);
+        else DK_REPART3_LAUNCH(1024, 8, 8);
     }
 #undef DK_SCAN_LAUNCH
-#undef DK_REPART_LAUNCH
 #undef DK_REPART3_LAUNCH
     DK_HIP(e, hipGetLastError());
     stage_mark(e, p.b3 ? "repart3" : "repart");
     return DK_OK;
+}
+
+// the piece list of slab `slab`'s regions (B.b holds one slab at a time; the region counts are indexed globally)
+template <class R>
+inline PieceList<R> slab_piece_list(const BucketPlan &p, const BucketBufs<R> &B, uint32_t slab)
+{
+    const uint64_t regions_per_slab = p.n_seg / p.slabs;
+    return PieceList<R>{B.rec, B.cursor2 + slab * regions_per_slab, 1, p.cap2, nullptr, nullptr};
 }
 
 // copy the device counters to the host; the absent tallies of the segment kernels (Counters::shard) are folded
@@ -311,8 +349,9 @@ inline dk_status sync_counters(dk_engine *e, const char *what)
         if (h == hipSuccess) h = hipStreamSynchronize(e->stream);     // the copy reads h_ctr, which the caller goes on to edit
         if (h != hipSuccess) return fail(e, DK_ERR_HIP, "%s failed: %s", what, hipGetErrorString(h));
     }
-    if (e->h_ctr->n_overflow)
-        return fail(e, DK_ERR_OVERFLOW, "bucket overflow (%llu records)", (unsigned long long)e->h_ctr->n_overflow);
+    if (e->h_ctr->n_overflow || e->h_ctr->n_sink_drop)
+        return fail(e, DK_ERR_OVERFLOW, "bucket overflow (%llu records)",
+                    (unsigned long long)(e->h_ctr->n_overflow + e->h_ctr->n_sink_drop));
     return DK_OK;
 }
 
@@ -328,22 +367,32 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
     using R = typename RecOf<WIDE>::type;
     BucketPlan p;
     const int T_full = set_segment_bits(e);
-    if (!make_plan(e, r, &p, 0, 0, pick_sub_bits(e, T_full))) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
+    if (!make_plan(e, r, &p, 0, 0, pick_sub_bits(e, T_full), true)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B, 0, 0, false);
     if (st == DK_OK) {
-        PieceList<R> pl{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
-        pl.sbits = p.sbits;
-        pl.sub_shift = 64 - T_full;
-        const unsigned n_seg = (unsigned)(p.n_seg << p.sbits);
-        if (s->exact)
-            seg_exact_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, T_full, e->d_ctr);
-        else
-            seg_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(
-                s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS);
-        hipError_t h = hipGetLastError();
+        // slab by slab (one slab = everything, unless the plan is slab-wise): level 2 of the slab's bins, then its segments
+        const uint64_t regions_per_slab = p.n_seg / p.slabs;
+        const unsigned n_seg = (unsigned)(regions_per_slab << p.sbits);
+        hipError_t h = hipSuccess;
+        for (uint32_t sl = 0; sl < p.slabs && h == hipSuccess; sl++) {
+            if (p.slabs > 1) {
+                launch_repart<WIDE>(e, p, B, 0, sl);
+                stage_mark(e, "repart");
+            }
+            PieceList<R> pl = slab_piece_list(p, B, sl);
+            pl.sbits = p.sbits;
+            pl.sub_shift = 64 - T_full;
+            const uint64_t seg_base = (uint64_t)sl * n_seg;
+            if (s->exact)
+                seg_exact_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, T_full, e->d_ctr, seg_base);
+            else
+                seg_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(
+                    s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS, seg_base);
+            h = hipGetLastError();
+            if (h == hipSuccess) stage_mark(e, s->exact ? "seg_exact_insert" : "seg_insert");
+        }
         if (h == hipSuccess) {
-            stage_mark(e, s->exact ? "seg_exact_insert" : "seg_insert");
             // overflow records (normally none): the kernel reads their number from device memory
             const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
             ovf_insert_kernel<R><<<e->n_cu * 2, DIRECT_BLOCK, 0, e->stream>>>(
@@ -364,7 +413,7 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
 // independent workgroups overlap their load / probe phases better than fewer, longer ones.)
 // the membership kernel of one batch over the n_seg segments from seg_base on (the set's kind and hash count pick the
 // instance); s == nullptr is only valid with ACC: every record is absent
-template <class R, bool ACC>
+template <class R, int ACC>
 inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &list, uint64_t n_seg, int T_full,
                                    uint64_t seg_base, const MissOut<R> &mo)
 {
@@ -388,32 +437,36 @@ inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &
 template <bool WIDE>
 inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename RecOf<WIDE>::type> &list, uint64_t n_units,
                                       int Tc, uint64_t unit_base, uint64_t n_absent, uint64_t extra_room, uint32_t min_count,
-                                      dk_result *res, uint64_t size_records = 0)
+                                      dk_result *res, uint64_t size_records = 0, bool packed = false)
 {
     if (!n_absent) return DK_OK;
     const uint64_t per_seg = n_absent / n_units;
+    // packed: `list` describes units of an accumulator's packed store (k <= 32 only)
+#define DK_COUNT_LAUNCH(TH, SLOTS, BM, PER_CU)                                                                                  \
+    do {                                                                                                                        \
+        const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * PER_CU);                               \
+        if (packed && !WIDE)                                                                                                    \
+            seg_count_kernel<TH, SLOTS, BM, WIDE, !WIDE><<<cgrid, TH, 0, e->stream>>>(                                          \
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
+        else                                                                                                                    \
+            seg_count_kernel<TH, SLOTS, BM, WIDE, false><<<cgrid, TH, 0, e->stream>>>(                                          \
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
+    } while (0)
     auto launch = [&](uint64_t region_cap) -> hipError_t {
         if (per_seg >= (e->opt.cnt_big > 0 ? (uint64_t)e->opt.cnt_big : (WIDE ? 3500u : 7000u))) {
             // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
-            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 2);
-            seg_count_kernel<1024, 2048, 8192, WIDE><<<cgrid, 1024, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
+            DK_COUNT_LAUNCH(1024, 2048, 8192, 2);
         } else if (per_seg >= (WIDE ? 1300u : (uint64_t)(e->opt.cnt_mid > 0 ? e->opt.cnt_mid : 3600))) {
-            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 6);
-            seg_count_kernel<512, 2048, 2048, WIDE><<<cgrid, 512, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
+            DK_COUNT_LAUNCH(512, 2048, 2048, 6);
         } else if (per_seg >= (WIDE ? 600u : 1200u)) {
             // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each
-            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 12);
-            seg_count_kernel<256, 1024, 1024, WIDE><<<cgrid, 256, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
+            DK_COUNT_LAUNCH(256, 1024, 1024, 12);
         } else {
-            const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * 32);
-            seg_count_kernel<128, 512, 256, WIDE><<<cgrid, 128, 0, e->stream>>>(
-                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);
+            DK_COUNT_LAUNCH(128, 512, 256, 32);
         }
         return hipGetLastError();
     };
+#undef DK_COUNT_LAUNCH
     // RESULT_REGIONS output regions, each with its own fill counter; segments are dealt to the
     // regions round-robin, so the regions fill evenly (12.5 % + 64 Ki entries of slack each);
     // overflow records may all sit in one segment, hence the extra room for them
@@ -490,7 +543,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
         int u = 0;
         const uint64_t n_sample = 64;
         if (p.cap2 > split_above && p.n_seg > 2 * n_sample && !e->opt.sink_plain) {
-            hipError_t h = launch_seg_probe<R, false>(e, s, list, n_sample, p.T, 0, mo);
+            hipError_t h = launch_seg_probe<R, ACC_NONE>(e, s, list, n_sample, p.T, 0, mo);
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
             if (st == DK_OK) st = sync_counters(e, "membership sample");
             if (st == DK_OK) {
@@ -521,7 +574,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
                         // a record whose unit is full only bumps n_overflow (no overflow list): the batch is then probed again
                         // the plain way
                         const MissOut<R> mf{store, cap_u, B.fine_cursor, u, 64 - p.T - u, OvfList<R>{nullptr, &e->d_ctr->dbg[0], 0}};
-                        if (h == hipSuccess) h = launch_seg_probe<R, true>(e, s, list, p.n_seg, p.T, 0, mf);
+                        if (h == hipSuccess) h = launch_seg_probe<R, ACC_PLAIN>(e, s, list, p.n_seg, p.T, 0, mf);
                         if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
                     }
                     if (st == DK_OK) {
@@ -532,9 +585,11 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
                             pool_free(e, B.fine);
                             B.fine_cursor = nullptr;
                             B.fine = nullptr;
-                            e->h_ctr->n_overflow = 0;
+                            e->h_ctr->n_overflow = e->h_ctr->n_sink_drop = 0;
                             e->h_ctr->n_absent = 0;
+                            snprintf(e->ev_name[e->n_ev - 1], sizeof e->ev_name[0], "seg_probe_sunk");   // the abandoned attempt
                             h = hipMemsetAsync(&e->d_ctr->n_overflow, 0, 8, e->stream);
+                            if (h == hipSuccess) h = hipMemsetAsync(&e->d_ctr->n_sink_drop, 0, 8, e->stream);
                             if (h == hipSuccess) h = hipMemsetAsync(&e->d_ctr->n_absent, 0, 8, e->stream);
                             st = h == hipSuccess ? DK_OK : fail(e, DK_ERR_HIP, "counter reset failed: %s", hipGetErrorString(h));
                         } else if (st == DK_OK) {
@@ -547,7 +602,7 @@ inline dk_status bucketed_probe_t(dk_engine *e, dk_set *s, const dk_reads *r, dk
             }
         }
         if (st == DK_OK && !sunk_fine) {
-            const hipError_t h = launch_seg_probe<R, false>(e, s, list, p.n_seg, p.T, 0, mo);
+            const hipError_t h = launch_seg_probe<R, ACC_NONE>(e, s, list, p.n_seg, p.T, 0, mo);
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
             else stage_mark(e, s->exact ? "seg_exact_probe" : "seg_probe");
             list = PieceList<R>{B.scratch, B.miss_cnt, 1, miss_cap, nullptr, nullptr};
@@ -671,57 +726,118 @@ inline MissOut<R> accum_out(dk_engine *e, const dk_accum *a)
 }
 inline int accum_unit_bits(const dk_accum *a) { return a->T + a->u; }
 inline uint64_t accum_unit_base(const dk_accum *a) { return (uint64_t)a->widx << (a->T - a->wbits + a->u); }
+inline size_t accum_rec_bytes(const dk_accum *a) { return a->wide ? sizeof(Rec2) : a->packed ? (size_t)PACKED_REC_BYTES : sizeof(Rec1); }
 
 // Partition the batch's records of the accumulator's hash window, test them against the set and append the absent
-// ones to the accumulator's units.  DK_ERR_OVERFLOW with nothing appended when the partition's overflow list
-// overflowed (the caller redoes the batch through the direct family); any other failure leaves the accumulator unusable.
+// ones to the accumulator's units -- slab by slab when the plan is slab-wise: one scan of the reads, then for every
+// slab of level-1 bins the second multisplit level and the membership kernel over the slab's segments.  No host
+// synchronisation before the end: a kernel that loses records (the partition's overflow list is full) raises
+// Counters::n_overflow / fail_mark on the device and every later membership launch of the batch returns at once
+// (batch_has_failed), so what reached the accumulator is exactly the slabs before the failing one.
+// Returns DK_OK, or DK_ERR_OVERFLOW with
+//   *fatal = true:  the accumulator itself lost records (units and overflow list full): it is unusable
+//   *fatal = false: the partition lost records in slab F; every k-mer of the window with hash < *redo_from has been
+//                   appended (*absent_done of them) and the caller redoes hashes >= *redo_from through the direct family
 template <bool WIDE>
-inline dk_status bucketed_accum_add_t(dk_engine *e, dk_accum *a, const dk_reads *r, bool *appended)
+inline dk_status bucketed_accum_add_t(dk_engine *e, dk_accum *a, const dk_reads *r, bool *fatal, uint64_t *redo_from,
+                                      uint64_t *absent_done)
 {
     using R = typename RecOf<WIDE>::type;
-    *appended = false;
+    *fatal = false;
+    *redo_from = a->wbits ? (uint64_t)a->widx << (64 - a->wbits) : 0;
+    *absent_done = 0;
     BucketPlan p;
     const int sbits = a->s ? pick_sub_bits(e, a->T - a->wbits) : 0;
-    if (!make_plan(e, r, &p, a->T, a->wbits, sbits)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
+    if (!make_plan(e, r, &p, a->T, a->wbits, sbits, true)) return fail(e, DK_ERR_UNSUPPORTED, "no bucketed plan for this geometry");
     BucketBufs<R> B;
     dk_status st = bucketed_partition<WIDE>(e, r, p, B, a->wbits, a->widx, false);
-    // nothing may be appended from a batch whose partition lost records: look before the membership kernel runs
-    if (st == DK_OK) st = sync_counters(e, "bucketed partition");
     if (st != DK_OK) { free_bufs(e, B); return st; }
-    PieceList<R> list{B.rec, B.cursor2, 1, p.cap2, nullptr, nullptr};
-    list.sbits = p.sbits;
-    list.sub_shift = 64 - a->T;
     const MissOut<R> mo = accum_out<R>(e, a);
-    const uint64_t seg_base = (uint64_t)a->widx << (a->T - a->wbits);
-    *appended = true;
-    hipError_t h = launch_seg_probe<R, true>(e, a->s, list, p.n_seg << p.sbits, a->T, seg_base, mo);
+    const uint64_t win_seg0 = (uint64_t)a->widx << (a->T - a->wbits);
+    const uint64_t regions_per_slab = p.n_seg / p.slabs, segs_per_slab = regions_per_slab << p.sbits;
+    const char *probe_name = a->s && a->s->exact ? "seg_exact_probe" : a->s ? "seg_probe" : "seg_append";
+    hipError_t h = hipSuccess;
+    for (uint32_t sl = 0; sl < p.slabs && h == hipSuccess; sl++) {
+        if (p.slabs > 1) {
+            launch_repart<WIDE>(e, p, B, a->wbits, sl);
+            stage_mark(e, "repart");
+        }
+        PieceList<R> list = slab_piece_list(p, B, sl);
+        list.sbits = p.sbits;
+        list.sub_shift = 64 - a->T;
+        // the slab's first unit inside the window: the sink addresses units from there
+        MissOut<R> ms = mo;
+        const uint64_t unit0 = ((uint64_t)sl * segs_per_slab) << a->u;
+        ms.cnt = mo.cnt + unit0;
+        ms.recs = (R *)((char *)mo.recs + unit0 * (uint64_t)a->unit_cap * accum_rec_bytes(a));
+        const uint64_t seg_base = win_seg0 + (uint64_t)sl * segs_per_slab;
+        bool launched = false;
+        if constexpr (!WIDE) {
+            if (a->packed) {
+                h = launch_seg_probe<R, ACC_PACKED>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
+                launched = true;
+            }
+        }
+        if (!launched) h = launch_seg_probe<R, ACC_PLAIN>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
+        if (h == hipSuccess) stage_mark(e, probe_name);
+    }
     if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "seg_probe launch failed: %s", hipGetErrorString(h));
-    else stage_mark(e, a->s && a->s->exact ? "seg_exact_probe" : a->s ? "seg_probe" : "seg_append");
+    if (st == DK_OK) st = sync_counters(e, "bucketed accumulate");
+    uint64_t h_lim = 0;                         // != 0: the partition failed in a later slab; hashes below are complete
+    if (st == DK_ERR_OVERFLOW) {
+        if (e->h_ctr->n_sink_drop) { *fatal = true; free_bufs(e, B); return st; }
+        const uint64_t F = 0xFFFFFFFFULL - (e->h_ctr->fail_mark & 0xFFFFFFFFULL);
+        const uint64_t bins_done = e->h_ctr->fail_mark && F < p.slabs ? F * p.slab_bins : 0;
+        if (!bins_done) { free_bufs(e, B); return st; }     // nothing is complete: the whole window is redone
+        h_lim = (((uint64_t)a->widx << p.b1) | bins_done) << (64 - a->wbits - p.b1);
+        *redo_from = h_lim;
+        st = DK_OK;
+        stage_mark(e, "slab_partial");
+    }
     // overflow records of the partition (normally none): probe one by one, append the absent ones through global cursors
     if (st == DK_OK && e->h_ctr->n_ovf) {
-        const uint64_t n_ovf = e->h_ctr->n_ovf;
+        const uint64_t n_ovf = std::min<uint64_t>(e->h_ctr->n_ovf, B.ovf_cap);
         st = pool_alloc(e, n_ovf * sizeof(R), (void **)&B.ovf_miss);
         if (st == DK_OK) {
             const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
             ovf_probe_kernel<R><<<grid_for(e, n_ovf, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
                 a->s ? a->s->d_words : nullptr, ovf, (int)e->cfg.filter_log2_bits - 9, (int)e->cfg.n_hashes,
-                a->s && a->s->exact ? a->T : 0, 1, 0, B.ovf_miss, nullptr, e->d_ctr);
+                a->s && a->s->exact ? a->T : 0, 1, 0, B.ovf_miss, nullptr, e->d_ctr, h_lim);
             h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow probe failed: %s", hipGetErrorString(h));
         }
-        if (st == DK_OK) st = sync_counters(e, "overflow probe");
+        if (st == DK_OK) {
+            // (the partition's n_overflow is still raised after a partial failure: read the counters without judging them)
+            h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
+            if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow probe failed: %s", hipGetErrorString(h));
+        }
         if (st == DK_OK && e->h_ctr->n_ovf_miss) {
             const uint64_t n_om = e->h_ctr->n_ovf_miss;
-            acc_append_kernel<R><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                B.ovf_miss, n_om, accum_unit_bits(a), accum_unit_base(a), mo, e->d_ctr);
+            if (a->packed && !WIDE)
+                acc_append_kernel<R, !WIDE><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    B.ovf_miss, n_om, accum_unit_bits(a), accum_unit_base(a), mo, e->d_ctr);
+            else
+                acc_append_kernel<R, false><<<grid_for(e, n_om, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    B.ovf_miss, n_om, accum_unit_bits(a), accum_unit_base(a), mo, e->d_ctr);
             h = hipGetLastError();
             if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow append failed: %s", hipGetErrorString(h));
             else stage_mark(e, "ovf_append");
         }
+        if (st == DK_OK) {
+            h = hipMemcpyAsync(e->h_ctr, e->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, e->stream);
+            if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow append failed: %s", hipGetErrorString(h));
+            else if (e->h_ctr->n_sink_drop) { *fatal = true; st = fail(e, DK_ERR_OVERFLOW, "accumulator full"); }
+        }
+        if (st == DK_OK) e->h_ctr->n_absent += e->h_ctr->n_ovf_miss;
     }
-    if (st == DK_OK) st = sync_counters(e, "bucketed accumulate");
-    if (st == DK_OK) e->h_ctr->n_absent += e->h_ctr->n_ovf_miss;
     free_bufs(e, B);
+    if (st == DK_OK && h_lim) {
+        *absent_done = e->h_ctr->n_absent;
+        return DK_ERR_OVERFLOW;
+    }
+    if (st != DK_OK && st != DK_ERR_UNSUPPORTED) *fatal = true;     // died half-way: appended or not is unknown
     return st;
 }
 

@@ -41,19 +41,21 @@ ovf_insert_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, i
 }
 
 // Probe the overflow records (filter == nullptr: every record counts as absent); absent ones are
-// appended to `miss` and tallied per segment for the CSR build.
+// appended to `miss` and tallied per segment for the CSR build.  h_lim != 0: only the records with h < h_lim (the slabs
+// of a slab-wise accumulate that completed before the partition lost records).
 template <class R>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 ovf_probe_kernel(unsigned long long *filter, OvfList<R> ovf, int log2_blocks, int n_hashes, int exact_T, int T,
-                 uint64_t unit_base, R *__restrict__ miss, uint32_t *seg_hist, Counters *ctr)
+                 uint64_t unit_base, R *__restrict__ miss, uint32_t *seg_hist, Counters *ctr, uint64_t h_lim = 0)
 {
     unsigned long long n = *ovf.count;
     if (n > ovf.cap) n = ovf.cap;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n_round = (n + 63) & ~63ULL;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        const bool have = i < n;
+        bool have = i < n;
         const R rec = ovf.recs[have ? i : 0];
+        if (h_lim && rec.h >= h_lim) have = false;
         bool absent = have;
         if (have && filter)
             absent = exact_T ? !exact_contains<sizeof(R) == 16>(filter, exact_T, rec.h, rec_hi(rec))
@@ -121,7 +123,7 @@ fill_sum_kernel(const uint32_t *__restrict__ fill, uint64_t n, uint32_t cap, uns
 }
 
 // append records (all of them absent, all inside the window) to their units: the absent overflow records of a batch
-template <class R>
+template <class R, bool PACKED>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 acc_append_kernel(const R *__restrict__ recs, uint64_t n, int T, uint64_t unit_base, MissOut<R> mo, Counters *ctr)
 {
@@ -136,20 +138,25 @@ acc_append_kernel(const R *__restrict__ recs, uint64_t n, int T, uint64_t unit_b
             const uint64_t unit = (rec.h >> (64 - T)) - unit_base;
             const uint32_t pos = atomicAdd(&mo.cnt[unit], 1u);       // may run past cap: readers clamp
             full = pos >= mo.cap;
-            if (!full) mo.recs[unit * mo.cap + pos] = rec;
+            if (!full) {
+                if constexpr (PACKED) packed_store(mo.recs, unit, mo.cap, pos, rec.h);
+                else mo.recs[unit * mo.cap + pos] = rec;
+            }
         }
         if (__ballot(full)) ovf_append(mo.ovf, full, rec, n_dropped);
     }
     n_dropped = (uint32_t)wave_sum(n_dropped);
-    if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
+    if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_sink_drop, (unsigned long long)n_dropped);
 }
 
 // the same for k-mers (the candidate list of the direct family: the exact redo path of a batch whose partition
-// overflowed); k-mers outside the window are skipped; the appended ones are tallied in Counters::shard
-template <bool WIDE>
+// overflowed); k-mers outside the window -- or below h_from, the part of the hash range that a slab-wise accumulate
+// had already completed -- are skipped; the appended ones are tallied in Counters::shard
+template <bool WIDE, bool PACKED>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 acc_append_kmers_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, uint64_t n, uint64_t seed,
-                        int wbits, uint32_t widx, int T, uint64_t unit_base, MissOut<typename RecOf<WIDE>::type> mo, Counters *ctr)
+                        int wbits, uint32_t widx, int T, uint64_t unit_base, MissOut<typename RecOf<WIDE>::type> mo, Counters *ctr,
+                        uint64_t h_from)
 {
     using R = typename RecOf<WIDE>::type;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -163,20 +170,24 @@ acc_append_kmers_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restr
         rec.h = fmix64((have ? lo[i] : 0) ^ hash_tweak<WIDE>(khi, seed));
         if constexpr (WIDE) rec.hi = khi;
         if (wbits && (uint32_t)(rec.h >> (64 - wbits)) != widx) have = false;
+        if (rec.h < h_from) have = false;
         bool full = false;
         if (have) {
             n_in++;
             const uint64_t unit = (rec.h >> (64 - T)) - unit_base;
             const uint32_t pos = atomicAdd(&mo.cnt[unit], 1u);
             full = pos >= mo.cap;
-            if (!full) mo.recs[unit * mo.cap + pos] = rec;
+            if (!full) {
+                if constexpr (PACKED) packed_store(mo.recs, unit, mo.cap, pos, rec.h);
+                else mo.recs[unit * mo.cap + pos] = rec;
+            }
         }
         if (__ballot(full)) ovf_append(mo.ovf, full, rec, n_dropped);
     }
     n_dropped = (uint32_t)wave_sum(n_dropped);
     n_in = wave_sum(n_in);
     if (lane_id() == 0) {
-        if (n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
+        if (n_dropped) atomicAdd(&ctr->n_sink_drop, (unsigned long long)n_dropped);
         if (n_in) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)n_in);
     }
 }

@@ -14,8 +14,11 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES, class R>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
-              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0, uint32_t bin_skew = 0)
+              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0, uint32_t bin_skew = 0,
+              uint32_t bin0 = 0, uint32_t slab = 0)
 {
+    // bin0 / slab: slab-wise partition (bucketed_partition) -- this launch covers the level-1 bins from bin0 on, and `out`
+    // holds the regions of these bins only (region (bin0 << b2) first); cursor2 is indexed by the region's global number
     constexpr int TILE = THREADS * PER_THREAD;
     constexpr int NB = THREADS >= MAX_BINS2 ? MAX_BINS2 : MAX_BINS;      // the bin scan is one thread per bin
     __shared__ SplitLds<THREADS, PER_THREAD, R, NB, false> L;
@@ -30,6 +33,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         b = 8 * (slot / per_bin) + (blockIdx.x & 7);
         bx = slot % per_bin;
     }
+    b += bin0;
     const uint32_t w = bx / tiles_per_piece, t0 = (bx % tiles_per_piece) * TILE;
     const uint64_t piece = (uint64_t)b * G + w;
     uint32_t n = cnt1[piece];
@@ -91,7 +95,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     }
     lds_barrier();                                       // C
     const uint32_t total = L.total;
-    const uint64_t seg0 = (uint64_t)b << b2;
+    const uint64_t seg0 = (uint64_t)(b - bin0) << b2;
     uint32_t n_overflow = 0;
     if (!L.ovf_seen) {
         // every segment region still has room for this tile: no bounds check, no overflow ballot
@@ -113,7 +117,10 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         }
     }
     n_overflow = (uint32_t)wave_sum(n_overflow);
-    if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
+    if (lane_id() == 0 && n_overflow) {
+        atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
+        atomicMax(&ctr->fail_mark, 0xFFFFFFFFULL - slab);     // the first slab that lost records (slab-wise accumulate: redone exactly)
+    }
 }
 
 }  // namespace dk

@@ -169,7 +169,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                 const uint32_t cu = tid < nbins ? L.cur[tid] : 0;
                 uint32_t below = 0;
 #pragma unroll
-                for (int v = 0; v < MAX_BINS / 64 - 1; v++) {
+                for (int v = 0; v < L.N_BINS / 64 - 1; v++) {
                     const uint32_t x = L.cnt[64 * v + lane];    // unconditional: the reads pipeline (cnt[] is zero beyond nbins)
                     below += v < wv ? x : 0u;
                 }
@@ -248,7 +248,10 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         if (tid == 0 && n_records) atomicAdd(&ctr->n_valid, (unsigned long long)n_records);
     }
     n_overflow = (uint32_t)wave_sum(n_overflow);
-    if (lane_id() == 0 && n_overflow) atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
+    if (lane_id() == 0 && n_overflow) {
+        atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
+        atomicMax(&ctr->fail_mark, 0xFFFFFFFFULL);           // records lost before any slab: everything is to be redone
+    }
 }
 
 // ---- kmer.rs stand-in at streaming speed: canonical k-mer / hash / not-a-k-mer bit per position ------------

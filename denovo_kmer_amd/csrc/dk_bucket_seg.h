@@ -136,14 +136,16 @@ __device__ __forceinline__ void stage_segment(uint32_t *seg, const SegRegs &r)
     for (int q = 0; q < SEG_VEC; q++) dst[q * SEG_THREADS + (int)threadIdx.x] = r.v[q];
 }
 
+// seg_base: the launch covers the segments seg_base .. seg_base + gridDim.x of the set (one slab of a slab-wise partition;
+// the piece list is indexed from the launch's first region)
 template <class R>
 DK_SEG_KERNEL
-seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift)
+seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift, uint64_t seg_base)
 {
     __shared__ __attribute__((aligned(16))) uint32_t seg[SEG_WORDS32];
     const uint64_t seg_id = segment_of_block();
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
-    const SegRegs sr = fetch_segment(filter, seg_id);
+    const SegRegs sr = fetch_segment(filter, seg_base + seg_id);
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) return;                       // nothing to add: leave the segment untouched
@@ -177,17 +179,17 @@ seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int
         fetch(i0);
     }
     __syncthreads();
-    uint4 *dst = (uint4 *)filter + seg_id * (SEG_BYTES / 16);
+    uint4 *dst = (uint4 *)filter + (seg_base + seg_id) * (SEG_BYTES / 16);
     const uint4 *s4 = (const uint4 *)seg;
     for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += SEG_THREADS) dst[i] = s4[i];
 }
 
 // Where the absent records of a segment go.
-//   per batch (ACC = false): recs[seg * cap ...], compacted per wave by ballot; cnt[seg] = their number
-//   accumulate (ACC = true, dk_accum_add): the accumulator's counting units of the segment -- unit = seg << sub_bits |
+//   per batch (ACC = 0): recs[seg * cap ...], compacted per wave by ballot; cnt[seg] = their number
+//   accumulate (ACC = 1 / 2, dk_accum_add): the accumulator's counting units of the segment -- unit = seg << sub_bits |
 //     the next sub_bits hash bits -- appended behind cnt[unit], which persists from batch to batch; a record whose unit
-//     is full goes to the accumulator's overflow list
-// seg = the segment's index inside the window (= blockIdx.x); the filter is addressed with seg_base + seg.
+//     is full goes to the accumulator's overflow list.  ACC = 2: the units hold PACKED records (below).
+// seg = the segment's index inside the launch (= blockIdx.x); the filter is addressed with seg_base + seg.
 template <class R>
 struct MissOut {
     R *recs;
@@ -198,8 +200,27 @@ struct MissOut {
 };
 constexpr int MAX_SUB_BITS = 10;
 constexpr int SUB_TALLY = 1 << MAX_SUB_BITS;       // index of the batch's absent tally behind the units' fills
+constexpr int ACC_NONE = 0, ACC_PLAIN = 1, ACC_PACKED = 2;
 
-template <class R, bool ACC>
+// Packed unit store (k <= 32, units of >= 16 implied prefix bits, i.e. every accumulator of a set of 2^28 bits or more):
+// all records of unit u share the top T + u bits of their hash, so only the low 48 bits are kept -- 6 bytes per
+// record instead of 8.  A unit of `cap` records is cap x u32 (hash bits 0..31) followed by cap x u16 (bits 32..47):
+// both arrays stay naturally aligned and every load / store instruction of a wave touches consecutive addresses.
+constexpr int PACKED_REC_BYTES = 6;
+constexpr int PACKED_MIN_PREFIX_BITS = 16;
+__device__ __forceinline__ void packed_store(void *store, uint64_t unit, uint32_t cap, uint32_t pos, uint64_t h)
+{
+    char *base = (char *)store + unit * (uint64_t)cap * PACKED_REC_BYTES;
+    ((uint32_t *)base)[pos] = (uint32_t)h;
+    ((uint16_t *)(base + (uint64_t)cap * 4))[pos] = (uint16_t)(h >> 32);
+}
+__device__ __forceinline__ uint64_t packed_load(const void *store, uint64_t unit, uint32_t cap, uint32_t pos, uint64_t prefix)
+{
+    const char *base = (const char *)store + unit * (uint64_t)cap * PACKED_REC_BYTES;
+    return prefix | ((uint64_t)((const uint16_t *)(base + (uint64_t)cap * 4))[pos] << 32) | ((const uint32_t *)base)[pos];
+}
+
+template <class R, int ACC>
 struct MissSink {
     uint32_t *sfill;       // LDS: ACC: fill of the segment's units; else [0] = absent records so far
     R *dst;
@@ -208,8 +229,8 @@ struct MissSink {
     uint32_t n_dropped = 0;
     __device__ __forceinline__ MissSink(uint32_t *lds, const MissOut<R> &m, uint64_t seg_local) : sfill(lds), mo(m), seg(seg_local)
     {
-        if constexpr (ACC) {
-            dst = m.recs + (seg_local << m.sub_bits) * (uint64_t)m.cap;
+        if constexpr (ACC != ACC_NONE) {
+            dst = ACC == ACC_PACKED ? m.recs : m.recs + (seg_local << m.sub_bits) * (uint64_t)m.cap;
             if (threadIdx.x < (1u << m.sub_bits)) sfill[threadIdx.x] = m.cnt[(seg_local << m.sub_bits) + threadIdx.x];
             if (threadIdx.x == 0) sfill[SUB_TALLY] = 0;                    // absent records of this batch
         } else {
@@ -220,14 +241,17 @@ struct MissSink {
     // every lane of the wave calls this (ballots inside)
     __device__ __forceinline__ void put(bool absent, const R &rec)
     {
-        if constexpr (ACC) {
+        if constexpr (ACC != ACC_NONE) {
             uint32_t sub = 0, pos = 0;
             if (absent) {
                 sub = (uint32_t)(rec.h >> mo.sub_shift) & ((1u << mo.sub_bits) - 1u);
                 pos = atomicAdd(&sfill[sub], 1u);
             }
             const bool full = absent && pos >= mo.cap;
-            if (absent && !full) dst[(uint64_t)sub * mo.cap + pos] = rec;
+            if (absent && !full) {
+                if constexpr (ACC == ACC_PACKED) packed_store(dst, (seg << mo.sub_bits) + sub, mo.cap, pos, rec.h);
+                else dst[(uint64_t)sub * mo.cap + pos] = rec;
+            }
             if (__ballot(full)) ovf_append(mo.ovf, full, rec, n_dropped);
         } else {
             const uint64_t b = __ballot(absent);
@@ -243,7 +267,7 @@ struct MissSink {
     // after a workgroup barrier; my_absent = absent records this thread saw (ACC only)
     __device__ __forceinline__ void finish(Counters *ctr, uint32_t my_absent)
     {
-        if constexpr (ACC) {
+        if constexpr (ACC != ACC_NONE) {
             const uint32_t ws = wave_total(my_absent);
             if (lane_id() == 0 && ws) atomicAdd(&sfill[SUB_TALLY], ws);
             lds_barrier();
@@ -253,7 +277,7 @@ struct MissSink {
             }
             if (threadIdx.x == 0 && sfill[SUB_TALLY]) atomicAdd(&ctr->shard[blockIdx.x % COUNTER_SHARDS], (unsigned long long)sfill[SUB_TALLY]);
             n_dropped = (uint32_t)wave_sum(n_dropped);
-            if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_overflow, (unsigned long long)n_dropped);
+            if (lane_id() == 0 && n_dropped) atomicAdd(&ctr->n_sink_drop, (unsigned long long)n_dropped);
         } else {
             if (threadIdx.x == 0) {
                 mo.cnt[seg] = sfill[0];
@@ -263,9 +287,17 @@ struct MissSink {
     }
 };
 
+// An accumulating launch gives up before it appends anything when an earlier kernel of the batch has lost records --
+// the partition of this slab or of an earlier one (Counters::n_overflow), or the sink of an earlier slab
+// (n_sink_drop): the host then knows exactly which slabs reached the accumulator (Counters::fail_mark) and redoes the rest.
+__device__ __forceinline__ bool batch_has_failed(const Counters *ctr)
+{
+    return (ctr->n_overflow | ctr->n_sink_drop) != 0;
+}
+
 // NH > 0: the number of hash bits is a compile-time constant (the four LDS reads of a record are then
 // issued back to back instead of one by one behind the short-circuit test); NH == 0: n_hashes at run time
-template <class R, int NH, bool ACC>
+template <class R, int NH, int ACC>
 DK_SEG_KERNEL
 seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
                  uint64_t seg_base, MissOut<R> mo, Counters *ctr)
@@ -277,6 +309,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
     SegRegs sr;
     if (!no_set) sr = fetch_segment(filter, seg_base + seg_id);
+    if (ACC != ACC_NONE && batch_has_failed(ctr)) return;
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) {
@@ -344,14 +377,14 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
 // Same shape as seg_insert / seg_probe: segment -> LDS, one LDS operation chain per record, segment back.
 template <class R>
 DK_SEG_KERNEL
-seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Counters *ctr)
+seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Counters *ctr, uint64_t seg_base)
 {
     constexpr bool WIDE = sizeof(R) == 16;
     static_assert(SEG_BYTES == EXACT_SEG_WORDS * 8, "exact segments are the filter segments");
     __shared__ __attribute__((aligned(16))) unsigned long long tab[EXACT_SEG_WORDS];
     const uint64_t seg_id = segment_of_block();
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
-    const SegRegs sr = fetch_segment(table, seg_id);
+    const SegRegs sr = fetch_segment(table, seg_base + seg_id);
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) return;
@@ -369,7 +402,7 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
     fetch(0);
     stage_segment((uint32_t *)tab, sr);
     __syncthreads();
-    const uint64_t EMPTY = exact_empty(seg_id, T);
+    const uint64_t EMPTY = exact_empty(seg_base + seg_id, T);
     uint32_t n_full = 0;
     for (uint32_t i0 = 0;;) {
 #pragma unroll
@@ -381,7 +414,7 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
         fetch(i0);
     }
     __syncthreads();
-    uint4 *dst = (uint4 *)table + seg_id * (SEG_BYTES / 16);
+    uint4 *dst = (uint4 *)table + (seg_base + seg_id) * (SEG_BYTES / 16);
     const uint4 *s4 = (const uint4 *)tab;
     for (int i = (int)threadIdx.x; i < SEG_BYTES / 16; i += SEG_THREADS) dst[i] = s4[i];
     n_full = (uint32_t)wave_sum(n_full);
@@ -392,7 +425,7 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
 // walk over the segments with the table and the records fetched in one round trip measured 6.8 ms
 // against 5.1 ms for this form at 2^17 segments: the hardware's workgroup scheduler overlaps the
 // segments' load / probe phases better than two resident persistent workgroups per CU do.)
-template <class R, bool ACC>
+template <class R, int ACC>
 DK_SEG_KERNEL
 seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T, uint64_t seg_base,
                        MissOut<R> mo, Counters *ctr)
@@ -403,6 +436,7 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
     const uint64_t seg_id = segment_of_block();
     const SegCounts sc = seg_counts(pl, seg_id >> pl.sbits);
     const SegRegs sr = fetch_segment(table, seg_base + seg_id);
+    if (ACC != ACC_NONE && batch_has_failed(ctr)) return;
     const SegPieces<R> sp = seg_pieces(pl, seg_id >> pl.sbits, sc);
     const uint32_t n = sp.total();
     if (n == 0) {

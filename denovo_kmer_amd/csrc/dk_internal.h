@@ -27,6 +27,12 @@ struct dk_options {
     int cnt_big = 0;              // seg_count: threshold of the 1024-thread geometry (default 7000, k > 32: 3500)
     int cnt_split_to = 0;         // absent-list split: records per unit aimed at (default 6000, k > 32: 3000)
     int repart_bits = 0;          // repart: most hash bits one pass may take (default 10; 9 = round 1's limit, for A/B runs)
+    int slabs = 0;                // slab-wise level 2 of insert / accumulate: number of slabs (0 = automatic; a power of two)
+    int slab_mb = 0;              // automatic slabs: room for one slab's regions in MiB (default 1024)
+    int ovf_cap = 0;              // capacity of the partition's overflow list in records (test hook; 0 = an eighth of the batch)
+    int accum_min_u = 0;          // dk_accum_create: at least 2^n counting units per segment (test hook: packed units on small sets)
+    int accum_plain = 0;          // dk_accum_create: 1 = never use packed 6-byte unit records (A/B runs, tests)
+    int scan_bits = 0;            // scan_part: most hash bits level 1 may take (default 10; 9 = round 2's limit, for A/B runs)
     int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
     int sub_split = 0;            // sub-segment split of the set kernels: 0 = automatic, 1..3 = force, 9 = never
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes
@@ -36,6 +42,7 @@ struct dk_options {
 };
 
 struct dk_comm;
+constexpr int DK_MAX_MARKS = 320;
 
 struct dk_engine {
     dk_config cfg;
@@ -50,9 +57,10 @@ struct dk_engine {
     dk::Counters *h_ctr;          // pinned host mirror
     std::vector<dk_pool_block> pool;
     // stage timing of the last operation
-    hipEvent_t ev[DK_MAX_STAGES + 1];
+    // (a slab-wise operation marks two stages per slab: the marks are summed by name into the dk_timings entries)
+    hipEvent_t ev[DK_MAX_MARKS + 1];
     int n_ev;
-    char ev_name[DK_MAX_STAGES][24];
+    char ev_name[DK_MAX_MARKS][24];
     dk_timings timings;
 };
 
@@ -90,6 +98,7 @@ struct dk_accum {
     unsigned long long *d_novf;   // device counter of the overflow list
     uint64_t n_absent, n_valid, n_windows, n_reads, n_bases, n_batches;
     bool wide;
+    bool packed;                  // units hold 6-byte packed records (k <= 32 and T + u >= 16; dk_bucket_seg.h)
     bool failed;                  // a batch lost records (overflow list full) or died half-way: reset before reuse
 };
 

@@ -45,6 +45,8 @@ struct Counters {               // device-side statistics of one operation
     unsigned long long dbg[8];      // DK_STAMPS diagnostic builds only: per-phase cycle sums
     unsigned long long region_fill[32];   // bucketed seg_count: entries written to each output region
     unsigned long long shard[32];         // bucketed seg_probe: absent records, tallied per workgroup (folded into n_absent on the host)
+    unsigned long long n_sink_drop;       // accumulate: absent records that found neither room in their unit nor in the accumulator's overflow list
+    unsigned long long fail_mark;         // slab-wise partition: 2^32 - 1 - (first slab whose partition dropped records); 0 = none did
 };
 
 // ---- ASCII -> packed stream ------------------------------------------------------------------

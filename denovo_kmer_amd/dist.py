@@ -148,18 +148,19 @@ def accum_exchange_finish(acc, min_count=1, group=None, stage_through_cpu=False)
     sizes = [int(x) for x in sizes.cpu()]
     extra, n_extra = None, sum(sizes)
     if n_extra:
+        ob = 16 if rb == 16 else 8          # the overflow list holds plain records (packed units: 6-byte records, 8 here)
         pad = max(sizes)
-        mine = torch.zeros(pad * rb, dtype=torch.uint8, device=dev)
+        mine = torch.zeros(pad * ob, dtype=torch.uint8, device=dev)
         if n_ovf:
-            mine[: n_ovf * rb] = _device_bytes(op, n_ovf * rb, dev)
+            mine[: n_ovf * ob] = _device_bytes(op, n_ovf * ob, dev)
         if stage_through_cpu:
-            g = torch.empty(world * pad * rb, dtype=torch.uint8)
+            g = torch.empty(world * pad * ob, dtype=torch.uint8)
             dist.all_gather_into_tensor(g, mine.cpu(), group=group)
             g = g.to(dev)
         else:
-            g = torch.empty(world * pad * rb, dtype=torch.uint8, device=dev)
+            g = torch.empty(world * pad * ob, dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(g, mine, group=group)
-        extra = torch.cat([g[r * pad * rb: (r * pad + sizes[r]) * rb] for r in range(world) if sizes[r]])
+        extra = torch.cat([g[r * pad * ob: (r * pad + sizes[r]) * ob] for r in range(world) if sizes[r]])
     torch.cuda.synchronize()
     res = acc.finish_pieces(recv_store.data_ptr(), recv_fill.data_ptr(), world, rank * upr, upr,
                             extra.data_ptr() if extra is not None else 0, n_extra, min_count)

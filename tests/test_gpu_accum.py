@@ -79,6 +79,98 @@ def test_accumulated_batches_equal_the_whole_sample(mode, k, set_kind, log2_bits
         ks.close()
 
 
+@pytest.mark.parametrize("k,set_kind", [(31, "bloom"), (45, "bloom"), (31, "exact")])
+@pytest.mark.parametrize("slabs,sub_split,window_count,min_u,plain", [(2, 0, 1, 8, 0), (2, 1, 1, 8, 1), (2, 0, 2, 9, 0), (0, 0, 1, 8, 0), (2, 0, 1, 0, 0)])
+def test_slab_wise_accumulate_and_packed_units(k, set_kind, slabs, sub_split, window_count, min_u, plain):
+    """the geometry of a whole-genome child pass on a small set: the level-1 bins are taken slab by slab (option "slabs"),
+    with and without the sub-segment split, and the accumulator keeps 6-byte packed records (units of >= 16 prefix bits:
+    option "accum_min_u"; "accum_plain" = 8-byte records); direct mode appends to the same units through global cursors"""
+    d = dk()
+    rng = np.random.default_rng(77 + k)
+    parents, child = related_trio(rng, genome_len=30000, n_reads=900, read_len=140)
+    child = child + child[:300] + ["", "ACGT", "N" * 40]
+    batches = ragged_batches(child, (0.2, 0.21, 0.7)) + [[]]
+    pseq, poff = orc.concat_reads(parents)
+    cseq, coff = orc.concat_reads(child)
+    log2_bits = 27 if set_kind == "bloom" else 28        # 2^8 / 2^9 segments: 16 level-1 bins, two slabs of 8
+    if set_kind == "bloom":
+        f = orc.new_filter(log2_bits)
+        orc.bloom_insert(f, log2_bits, 4, 5, k, True, pseq, poff)
+        km, cn, ost = orc.bloom_probe(f, log2_bits, 4, 5, k, True, cseq, coff, 1)
+    else:
+        km, cn, ost = orc.exact_child_only(k, True, pseq, poff, cseq, coff, 1)
+    for mode in ("bucketed", "direct"):
+        with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=5, mode=mode, set_kind=set_kind) as eng:
+            for name, val in (("slabs", slabs), ("sub_split", sub_split), ("accum_min_u", min_u), ("accum_plain", plain)):
+                eng.set_option(name, val)
+            ks = d.KmerSet(eng)
+            ks.insert_sequences(parents)
+            if set_kind == "bloom":
+                assert np.array_equal(ks.to_host(), f)          # (the insert ran slab-wise too)
+            acc = d.ChildAccumulator(eng, ks, capacity_records=400_000, window_count=window_count)
+            n_units, cap, rb = acc.geometry()
+            assert rb == (16 if k > 32 else 6 if (min_u >= 8 and not plain) else 8)
+            got, n_absent = {}, 0
+            for w in range(window_count):
+                acc.reset(w)
+                for b in batches:
+                    acc.add(d.ReadBatch.from_sequences(eng, b))
+                    names = [n for n, _ in eng.timings()["stages"]]
+                    if b and mode == "bucketed":
+                        assert names[:3] == ["scan_part", "repart", "seg_exact_probe" if set_kind == "exact" else "seg_probe"], names
+                        assert "overflow_redo" not in names, names
+                res = acc.finish(min_count=1)
+                got.update(table_of(res))
+                n_absent += res.stats["n_absent"]
+                res.close()
+            assert got == oracle_table(km, cn)
+            assert n_absent == ost["n_absent"]
+            acc.close()
+            ks.close()
+
+
+@pytest.mark.parametrize("seed", [5, 6, 7, 8])
+def test_partition_failure_in_a_later_slab_is_redone_exactly(seed):
+    """a slab-wise accumulate whose partition loses records in slab F (overflow list full: here 1000 entries against
+    40 000 copies of poly-A, all in one region) has appended the slabs before F; the rest of the hash range is redone by
+    the direct family and nothing is counted twice.  Two slabs: poly-A's slab is the top bit of its hash (seeds 5, 6: the
+    second slab -- the first one stays; seeds 7, 8: the first -- everything is redone)."""
+    d = dk()
+    k = 21
+    rng = np.random.default_rng(seed)
+    parents = random_reads(rng, 300, 150, 151)
+    # (one poly-A read in eleven: spread over the tiles, its records fit the level-1 pieces and overflow only their region)
+    base = random_reads(rng, 3000, 150, 151) + parents[:100]
+    child = []
+    for i, rd in enumerate(base):
+        child.append(rd)
+        if i % 10 == 0:
+            child.append("A" * 150)
+    pseq, poff = orc.concat_reads(parents)
+    cseq, coff = orc.concat_reads(child)
+    f = orc.new_filter(27)
+    orc.bloom_insert(f, 27, 4, seed, k, True, pseq, poff)
+    km, cn, ost = orc.bloom_probe(f, 27, 4, seed, k, True, cseq, coff, 1)
+    in_second_slab = bool(orc.hash_kmer(0, 0, k, seed) >> 63)
+    assert in_second_slab == (seed in (5, 6))
+    for plain in (0, 1):
+        with d.Engine(k=k, filter_log2_bits=27, n_hashes=4, seed=seed, mode="bucketed") as eng:
+            for name, val in (("slabs", 2), ("ovf_cap", 1000), ("accum_min_u", 8), ("accum_plain", plain)):
+                eng.set_option(name, val)
+            ks = d.KmerSet(eng)
+            ks.insert_sequences(parents)
+            acc = d.ChildAccumulator(eng, ks, capacity_records=60_000_000)
+            st = acc.add(d.ReadBatch.from_sequences(eng, child))
+            names = [n for n, _ in eng.timings()["stages"]]
+            assert "overflow_redo" in names and ("slab_partial" in names) == in_second_slab, names
+            assert st["n_valid"] == ost["n_valid"] and st["n_absent"] == ost["n_absent"]
+            res = acc.finish()
+            assert table_of(res) == oracle_table(km, cn)
+            res.close()
+            acc.close()
+            ks.close()
+
+
 @pytest.mark.parametrize("mode", ["direct", "bucketed"])
 @pytest.mark.parametrize("k", [31, 51])
 def test_accumulating_kmer_counter_without_a_set(mode, k):
