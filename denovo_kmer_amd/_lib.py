@@ -22,7 +22,7 @@ MODE_AUTO, MODE_DIRECT, MODE_BUCKETED = 0, 1, 2
 SET_BLOOM, SET_EXACT = 0, 1
 ERR_SET_FULL = 7
 MAX_STAGES = 12
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class DkError(RuntimeError):
@@ -81,6 +81,12 @@ SYMBOLS = {
     "dk_engine_config": (C.c_int32, [_P, C.POINTER(DkConfig)]),
     "dk_engine_set_option": (C.c_int32, [_P, C.c_char_p, C.c_int64]),
     "dk_engine_trim": (C.c_int32, [_P, _PU64]),
+    "dk_engine_get_info": (C.c_int32, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "dk_engine_reserve": (C.c_int32, [_P, _U64]),
+    "dk_reads_from_packed_async": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),
+    "dk_reads_wait": (C.c_int32, [_P]),
+    "dk_host_alloc": (C.c_int32, [_U64, _PP]),
+    "dk_host_free": (None, [_P]),
     "dk_reads_from_ascii": (C.c_int32, [_P, _P, _P, _U64, _PP]),
     "dk_reads_from_packed": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),
     "dk_reads_attach_device": (C.c_int32, [_P, _P, _P, _U64, _U64, _U64, _PP]),
@@ -108,6 +114,7 @@ SYMBOLS = {
     "dk_comm_init": (C.c_int32, [_P, _P, C.c_uint32, C.c_uint32]),
     "dk_comm_finalize": (C.c_int32, [_P]),
     "dk_set_allreduce_or": (C.c_int32, [_P, _PU64]),
+    "dk_comm_layout": (C.c_int32, [_U64, _U64, C.c_uint32, C.c_uint32, _U64, _PU64, _PU64]),
     "dk_probe": (C.c_int32, [_P, _P, _P, _PP, C.POINTER(DkStats)]),
     "dk_result_size": (C.c_int32, [_P, _PU64]),
     "dk_result_copy": (C.c_int32, [_P, _P, _P, _P]),
@@ -123,6 +130,7 @@ SYMBOLS = {
     "dk_accum_geometry": (C.c_int32, [_P, _PU64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "dk_accum_device_view": (C.c_int32, [_P, _PP, _PP, _PP, _PU64]),
     "dk_accum_finish_pieces": (C.c_int32, [_P, _P, _P, C.c_uint32, _U64, _U64, _P, _U64, C.c_uint32, _PP, C.POINTER(DkStats)]),
+    "dk_accum_exchange_finish": (C.c_int32, [_P, C.c_uint32, _PP, C.POINTER(DkStats), _PU64]),
     "dk_accum_device_bytes": (C.c_int32, [_P, _PU64]),
     "dk_accum_destroy": (None, [_P]),
 }

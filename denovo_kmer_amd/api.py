@@ -96,6 +96,17 @@ class Engine:
         self.check(self._lib.dk_engine_trim(self.handle, C.byref(n)))
         return int(n.value)
 
+    def reserve(self, n_bytes):
+        """allocate one arena of n_bytes now; every later workspace / batch / set / accumulator of the engine is carved
+        from it (dk_engine_reserve); 0 hands back the arenas nothing lives in"""
+        self.check(self._lib.dk_engine_reserve(self.handle, int(n_bytes)))
+
+    def info(self, name):
+        """what the engine did / holds (dk_engine_get_info): "plan_slabs", "plan_sbits", "pool_bytes_in_use", ..."""
+        v = C.c_int64()
+        self.check(self._lib.dk_engine_get_info(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
     @staticmethod
     def comm_unique_id():
         """128-byte RCCL id (dk_comm_unique_id): one rank creates it, the host hands it to the others"""
@@ -153,6 +164,33 @@ def synth_config(seed=20260313, genome_len=50_000, read_len=150, snv_rate=1e-3, 
                          thr(snv_rate), thr(denovo_rate), thr(err_rate), thr(n_rate))
 
 
+class PinnedPacked:
+    """Pinned host memory (dk_host_alloc) holding one packed batch -- bases words then mask words -- for
+    ReadBatch.from_packed_async; `bases` / `mask` are numpy views of it"""
+
+    def __init__(self, n_bases):
+        self._lib = _lib.load()
+        self.n_bwords, self.n_mwords = (n_bases + 31) // 32, (n_bases + 63) // 64
+        self._p = C.c_void_p()
+        check(self._lib.dk_host_alloc((self.n_bwords + self.n_mwords) * 8, C.byref(self._p)))
+        buf = (C.c_uint64 * (self.n_bwords + self.n_mwords)).from_address(self._p.value)
+        whole = np.frombuffer(buf, dtype=np.uint64)
+        self.bases, self.mask = whole[:self.n_bwords], whole[self.n_bwords:]
+        self.bases_ptr, self.mask_ptr = self._p.value, self._p.value + self.n_bwords * 8
+
+    def close(self):
+        if self._p:
+            self.bases = self.mask = None
+            self._lib.dk_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ReadBatch:
     """A device-resident packed read batch (dk_reads)."""
 
@@ -184,6 +222,19 @@ class ReadBatch:
         engine.check(engine._lib.dk_reads_from_packed(engine.handle, _vp(bases), _vp(mask), n_bases,
                                                       n_reads, n_windows, C.byref(h)))
         return cls(engine, h)
+
+    @classmethod
+    def from_packed_async(cls, engine, pinned, n_bases, n_reads, n_windows):
+        """overlapped upload (dk_reads_from_packed_async) from a PinnedPacked host buffer, which must stay untouched
+        until wait() returns; whatever consumes the batch waits for the copy on the device"""
+        h = C.c_void_p()
+        engine.check(engine._lib.dk_reads_from_packed_async(engine.handle, C.c_void_p(pinned.bases_ptr), C.c_void_p(pinned.mask_ptr),
+                                                            n_bases, n_reads, n_windows, C.byref(h)))
+        return cls(engine, h, pinned)
+
+    def wait(self):
+        """block until an asynchronous upload of this batch has finished (dk_reads_wait)"""
+        self.engine.check(self.engine._lib.dk_reads_wait(self._h))
 
     @classmethod
     def attach_device(cls, engine, d_bases, d_mask, n_bases, n_reads, n_windows, keepalive=None):
@@ -476,7 +527,21 @@ class ChildAccumulator:
         self.engine.check(self.engine._lib.dk_accum_finish_pieces(
             self._h, C.c_void_p(stores_ptr), C.c_void_p(fills_ptr), n_pieces, first_unit, n_units,
             C.c_void_p(extra_ptr) if extra_ptr else None, n_extra, min_count, C.byref(h), C.byref(st)))
-        return KmerCounts(self.engine, h, st.as_dict())
+        res = KmerCounts(self.engine, h, st.as_dict())
+        res._keep = keepalive            # (the result does not reference the pieces, but callers may want them to live as long)
+        return res
+
+    def exchange_finish(self, min_count=1):
+        """multi-GPU, collective (dk_accum_exchange_finish): the ranks swap unit ranges on the engine's communicator, in
+        place, and each counts its share of the hash space; the accumulator is consumed (reset before reuse).
+        -> KmerCounts; .bytes_sent = what this rank sent"""
+        h = C.c_void_p()
+        st = DkStats()
+        sent = C.c_uint64()
+        self.engine.check(self.engine._lib.dk_accum_exchange_finish(self._h, min_count, C.byref(h), C.byref(st), C.byref(sent)))
+        res = KmerCounts(self.engine, h, st.as_dict())
+        res.bytes_sent = int(sent.value)
+        return res
 
     def stats(self):
         st = DkStats()

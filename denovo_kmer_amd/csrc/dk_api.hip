@@ -27,11 +27,76 @@ dk_status fail(dk_engine *e, dk_status s, const char *fmt, ...)
     return s;
 }
 
-// ---- caching device allocator (grow-only; blocks are reused across operations) ---------------
+// ---- device memory: reserved arenas first (dk_engine_reserve), then the caching pool (grow-only; blocks are reused
+// across operations) ---------------
+static uint64_t pool_in_use(const dk_engine *e)
+{
+    uint64_t n = 0;
+    for (const auto &b : e->pool) if (b.in_use) n += b.bytes;
+    for (const auto &a : e->arenas)
+        for (const auto &g : a.segs) if (g.in_use) n += g.bytes;
+    return n;
+}
+
+static void *arena_alloc(dk_engine *e, size_t bytes)
+{
+    // big blocks on 2-MiB boundaries (whole pages), small ones on 256 bytes
+    const size_t align = bytes >= (8u << 20) ? (2u << 20) : 256;
+    dk_arena *best_a = nullptr;
+    size_t best_i = 0, best_bytes = ~(size_t)0, best_pad = 0;
+    for (auto &a : e->arenas)
+        for (size_t i = 0; i < a.segs.size(); i++) {
+            const dk_arena_seg &g = a.segs[i];
+            if (g.in_use) continue;
+            const size_t start = ((uintptr_t)a.base + g.off + align - 1) / align * align - (uintptr_t)a.base;
+            const size_t pad = start - g.off;
+            if (g.bytes < pad + bytes || g.bytes >= best_bytes) continue;
+            best_a = &a; best_i = i; best_bytes = g.bytes; best_pad = pad;
+        }
+    if (!best_a) return nullptr;
+    std::vector<dk_arena_seg> &v = best_a->segs;
+    if (best_pad) {                                          // the alignment gap stays a free segment of its own
+        const dk_arena_seg g = v[best_i];
+        v[best_i].bytes = best_pad;
+        v.insert(v.begin() + best_i + 1, dk_arena_seg{g.off + best_pad, g.bytes - best_pad, false});
+        best_i++;
+    }
+    if (v[best_i].bytes > bytes) {
+        const dk_arena_seg g = v[best_i];
+        v[best_i].bytes = bytes;
+        v.insert(v.begin() + best_i + 1, dk_arena_seg{g.off + bytes, g.bytes - bytes, false});
+    }
+    v[best_i].in_use = true;
+    return best_a->base + v[best_i].off;
+}
+
+static bool arena_free(dk_engine *e, void *p)
+{
+    for (auto &a : e->arenas) {
+        if ((char *)p < a.base || (char *)p >= a.base + a.bytes) continue;
+        std::vector<dk_arena_seg> &v = a.segs;
+        const size_t off = (size_t)((char *)p - a.base);
+        for (size_t i = 0; i < v.size(); i++) {
+            if (v[i].off != off) continue;
+            v[i].in_use = false;
+            if (i + 1 < v.size() && !v[i + 1].in_use) { v[i].bytes += v[i + 1].bytes; v.erase(v.begin() + i + 1); }
+            if (i > 0 && !v[i - 1].in_use) { v[i - 1].bytes += v[i].bytes; v.erase(v.begin() + i); }
+            return true;
+        }
+        return true;                                         // inside the arena but not a segment start: ignore
+    }
+    return false;
+}
+
 dk_status pool_alloc(dk_engine *e, size_t bytes, void **out)
 {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~(size_t)255;
+    if (void *p = arena_alloc(e, bytes)) {
+        *out = p;
+        e->pool_peak = std::max<uint64_t>(e->pool_peak, pool_in_use(e));
+        return DK_OK;
+    }
     int best = -1;
     for (size_t i = 0; i < e->pool.size(); i++) {
         dk_pool_block &b = e->pool[i];
@@ -41,6 +106,7 @@ dk_status pool_alloc(dk_engine *e, size_t bytes, void **out)
     if (best >= 0) {
         e->pool[best].in_use = true;
         *out = e->pool[best].ptr;
+        e->pool_peak = std::max<uint64_t>(e->pool_peak, pool_in_use(e));
         return DK_OK;
     }
     void *p = nullptr;
@@ -61,12 +127,14 @@ dk_status pool_alloc(dk_engine *e, size_t bytes, void **out)
     }
     e->pool.push_back({p, bytes, true});
     *out = p;
+    e->pool_peak = std::max<uint64_t>(e->pool_peak, pool_in_use(e));
     return DK_OK;
 }
 
 void pool_free(dk_engine *e, void *p)
 {
     if (!p) return;
+    if (arena_free(e, p)) return;
     for (auto &b : e->pool)
         if (b.ptr == p) { b.in_use = false; return; }
 }
@@ -138,6 +206,13 @@ static StreamView view_of(const dk_reads *r)
     s.n_bwords = (r->n_bases + 31) / 32;
     s.n_mwords = (r->n_bases + 63) / 64;
     return s;
+}
+
+// a batch that is still being uploaded (dk_reads_from_packed_async): the engine's stream waits for the copy stream
+static dk_status reads_ready(dk_engine *e, const dk_reads *r)
+{
+    if (r->ready) DK_HIP(e, hipStreamWaitEvent(e->stream, r->ready, 0));
+    return DK_OK;
 }
 
 // exact sets: number of 64-KiB segments = 2^T
@@ -521,10 +596,14 @@ void dk_engine_destroy(dk_engine *e)
     (void)dk_comm_finalize(e);
     for (auto &b : e->pool)
         if (b.ptr) (void)hipFree(b.ptr);
+    for (auto &a : e->arenas)
+        if (a.base) (void)hipFree(a.base);
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    if (e->copy_ev) (void)hipEventDestroy(e->copy_ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -572,6 +651,52 @@ dk_status dk_engine_trim(dk_engine *e, uint64_t *bytes_freed)
     return DK_OK;
 }
 
+dk_status dk_engine_reserve(dk_engine *e, uint64_t bytes)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    DK_HIP(e, hipSetDevice(e->device));
+    if (bytes == 0) {
+        // hand back every arena nothing lives in
+        DK_HIP(e, hipStreamSynchronize(e->stream));
+        for (auto &a : e->arenas)
+            if (a.segs.size() == 1 && !a.segs[0].in_use) { (void)hipFree(a.base); a.base = nullptr; }
+        e->arenas.erase(std::remove_if(e->arenas.begin(), e->arenas.end(), [](const dk_arena &a) { return a.base == nullptr; }),
+                        e->arenas.end());
+        return DK_OK;
+    }
+    bytes = (bytes + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1);
+    void *p = nullptr;
+    const hipError_t r = hipMalloc(&p, bytes);
+    if (r != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e, DK_ERR_OOM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(r));
+    }
+    dk_arena a;
+    a.base = (char *)p;
+    a.bytes = bytes;
+    a.segs.push_back(dk_arena_seg{0, (size_t)bytes, false});
+    e->arenas.push_back(a);
+    return DK_OK;
+}
+
+dk_status dk_engine_get_info(const dk_engine *e, const char *name, int64_t *value)
+{
+    if (!e || !name || !value) return DK_ERR_INVALID_ARG;
+    const dk_plan_info &p = e->plan;
+    uint64_t cached = 0, reserved = 0;
+    for (const auto &b : e->pool) cached += b.bytes;
+    for (const auto &a : e->arenas) reserved += a.bytes;
+    const struct { const char *name; int64_t v; } info[] = {
+        {"plan_levels", p.levels}, {"plan_b1", p.b1}, {"plan_b2", p.b2}, {"plan_b3", p.b3}, {"plan_sbits", p.sbits},
+        {"plan_slabs", p.slabs}, {"plan_scan_variant", p.scan_variant}, {"plan_segment_bits", p.T},
+        {"pool_bytes_in_use", (int64_t)pool_in_use(e)}, {"pool_bytes_cached", (int64_t)cached},
+        {"pool_bytes_reserved", (int64_t)reserved}, {"pool_bytes_peak", (int64_t)e->pool_peak},
+    };
+    for (const auto &i : info)
+        if (strcmp(name, i.name) == 0) { *value = i.v; return DK_OK; }
+    return DK_ERR_INVALID_ARG;
+}
+
 dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
 {
     if (!e) return DK_ERR_INVALID_ARG;
@@ -596,6 +721,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"ovf_cap", &dk_options::ovf_cap, 0, 1 << 30},
         {"accum_plain", &dk_options::accum_plain, 0, 1},
         {"accum_min_u", &dk_options::accum_min_u, 0, 10},
+        {"mode", &dk_options::mode, 0, 2},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},
@@ -710,6 +836,62 @@ dk_status dk_reads_from_packed(dk_engine *e, const uint64_t *bases, const uint64
     return DK_OK;
 }
 
+// Overlapped ingest: the copies run on the engine's copy stream and the call returns at once; every operation that
+// consumes the batch makes the engine's stream wait for them, so batch i + 1 travels over PCIe while batch i is being
+// probed.  The host buffers must stay valid and unchanged until dk_reads_wait returns; they should be pinned
+// (dk_host_alloc), or the runtime stages the copy and the call blocks.
+dk_status dk_reads_from_packed_async(dk_engine *e, const uint64_t *bases, const uint64_t *mask,
+                                     uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out)
+{
+    if (!e) return DK_ERR_INVALID_ARG;
+    CHECK_ARG(e, out != nullptr);
+    CHECK_ARG(e, (bases != nullptr && mask != nullptr) || n_bases == 0);
+    *out = nullptr;
+    if (n_bases && !((mask[(n_bases - 1) >> 6] >> (63 - ((n_bases - 1) & 63))) & 1ULL))
+        return fail(e, DK_ERR_INVALID_ARG, "packed stream does not end with a flagged separator position");
+    DK_HIP(e, hipSetDevice(e->device));
+    if (!e->copy_stream) DK_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    if (!e->copy_ev) DK_HIP(e, hipEventCreateWithFlags(&e->copy_ev, hipEventDisableTiming));
+    dk_reads *r = nullptr;
+    DK_TRY(reads_alloc(e, n_bases, n_reads, n_windows, &r));
+    hipError_t h = hipEventCreateWithFlags(&r->ready, hipEventDisableTiming);
+    if (h == hipSuccess && n_bases) {
+        // the block may have served an operation that is still running on the engine's stream: copy after it
+        h = hipEventRecord(e->copy_ev, e->stream);
+        if (h == hipSuccess) h = hipStreamWaitEvent(e->copy_stream, e->copy_ev, 0);
+        if (h == hipSuccess) h = hipMemcpyAsync(r->d_bases, bases, (n_bases + 31) / 32 * 8, hipMemcpyHostToDevice, e->copy_stream);
+        if (h == hipSuccess) h = hipMemcpyAsync(r->d_mask, mask, (n_bases + 63) / 64 * 8, hipMemcpyHostToDevice, e->copy_stream);
+    }
+    if (h == hipSuccess) h = hipEventRecord(r->ready, e->copy_stream);
+    if (h != hipSuccess) {
+        dk_reads_destroy(r);
+        return fail(e, DK_ERR_HIP, "uploading packed reads failed: %s", hipGetErrorString(h));
+    }
+    *out = r;
+    return DK_OK;
+}
+
+dk_status dk_reads_wait(dk_reads *r)
+{
+    if (!r) return DK_ERR_INVALID_ARG;
+    if (r->ready) DK_HIP(r->e, hipEventSynchronize(r->ready));
+    return DK_OK;
+}
+
+dk_status dk_host_alloc(uint64_t bytes, void **out)
+{
+    if (!out) return DK_ERR_INVALID_ARG;
+    *out = nullptr;
+    const hipError_t h = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+    if (h != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, DK_ERR_OOM, "hipHostMalloc(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(h)); }
+    return DK_OK;
+}
+
+void dk_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 dk_status dk_reads_attach_device(dk_engine *e, const void *d_bases, const void *d_mask,
                                  uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out)
 {
@@ -798,6 +980,7 @@ dk_status dk_reads_download(const dk_reads *r, uint64_t *bases, uint64_t *mask)
     dk_engine *e = r->e;
     CHECK_ARG(e, (bases && mask) || r->n_bases == 0);
     DK_HIP(e, hipSetDevice(e->device));
+    DK_TRY(reads_ready(e, r));
     if (r->n_bases) {
         DK_HIP(e, hipMemcpyAsync(bases, r->d_bases, (r->n_bases + 31) / 32 * 8, hipMemcpyDeviceToHost, e->stream));
         DK_HIP(e, hipMemcpyAsync(mask, r->d_mask, (r->n_bases + 63) / 64 * 8, hipMemcpyDeviceToHost, e->stream));
@@ -840,6 +1023,7 @@ dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, ui
 {
     if (!e) return DK_ERR_INVALID_ARG;
     CHECK_ARG(e, r != nullptr && r->e == e);
+    DK_TRY(reads_ready(e, r));
     const bool wide = e->cfg.k > 32;
     CHECK_ARG(e, r->n_bases == 0 || kmers_lo != nullptr);
     constexpr int KT = 256;                                  // 4 waves, 35 KiB of LDS: four workgroups per CU
@@ -891,6 +1075,10 @@ dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, ui
 void dk_reads_destroy(dk_reads *r)
 {
     if (!r) return;
+    if (r->ready) {
+        (void)hipEventSynchronize(r->ready);       // the blocks go back to the pool: the upload must have left them
+        (void)hipEventDestroy(r->ready);
+    }
     if (r->owns) {
         pool_free(r->e, r->d_bases);
         pool_free(r->e, r->d_mask);
@@ -985,10 +1173,17 @@ dk_status dk_set_clear(dk_set *s)
     return DK_OK;
 }
 
+// the kernel family in force: the engine's configured mode unless option "mode" overrides it (1 = direct, 2 = bucketed;
+// bench.py checks a small sample against the oracle through the family that a full-size batch takes)
+static uint32_t mode_of(const dk_engine *e)
+{
+    return e->opt.mode == 1 ? (uint32_t)DK_MODE_DIRECT : e->opt.mode == 2 ? (uint32_t)DK_MODE_BUCKETED : e->cfg.mode;
+}
+
 static bool use_bucketed(const dk_engine *e, const dk_reads *r)
 {
-    if (e->cfg.mode == DK_MODE_DIRECT) return false;
-    if (e->cfg.mode == DK_MODE_BUCKETED) return true;
+    if (mode_of(e) == DK_MODE_DIRECT) return false;
+    if (mode_of(e) == DK_MODE_BUCKETED) return true;
     return dk::bucketed_pays(e, r->n_bases);
 }
 
@@ -998,6 +1193,7 @@ dk_status dk_set_insert(dk_set *s, const dk_reads *r, dk_stats *stats)
     dk_engine *e = s->e;
     CHECK_ARG(e, r->e == e);
     DK_HIP(e, hipSetDevice(e->device));
+    DK_TRY(reads_ready(e, r));
     DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
     stage_begin(e);
     if (r->n_bases) {
@@ -1277,6 +1473,7 @@ dk_status dk_comm_init(dk_engine *e, const uint8_t *id, uint32_t rank, uint32_t 
     c->world = world_size;
     c->staging = nullptr;
     c->staging_bytes = 0;
+    c->dead = false;
     if (world_size > 1 || id != nullptr) {       // (one rank WITH an id: a real communicator of one, see set_allreduce)
         RcclApi *api = rccl();
         if (!api->lib) { delete c; return fail(e, DK_ERR_UNSUPPORTED, "%s", api->err.c_str()); }
@@ -1330,6 +1527,7 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
     CHECK_ARG(e, r->e == e && (!s || s->e == e));
     *out = nullptr;
     DK_HIP(e, hipSetDevice(e->device));
+    DK_TRY(reads_ready(e, r));
     dk_result *res = new (std::nothrow) dk_result();
     if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
     res->e = e;
@@ -1350,7 +1548,7 @@ dk_status dk_probe(dk_engine *e, dk_set *s, const dk_reads *r, dk_result **out, 
         // KmerCounter (no set) partitions by batch size, not by the filter geometry: the bucketed family
         // pays from a few million positions on, whatever the engine's filter size
         bool direct = s ? !use_bucketed(e, r)
-                        : e->cfg.mode == DK_MODE_DIRECT || (e->cfg.mode == DK_MODE_AUTO && r->n_bases < (1ULL << 22));
+                        : mode_of(e) == DK_MODE_DIRECT || (mode_of(e) == DK_MODE_AUTO && r->n_bases < (1ULL << 22));
         if (!direct) {
             st = dk::bucketed_probe(e, s, r, res);
             if (st == DK_ERR_OVERFLOW) {
@@ -1413,6 +1611,7 @@ static dk_status accum_clear(dk_accum *a)
     DK_HIP(e, hipStreamSynchronize(e->stream));
     a->n_absent = a->n_valid = a->n_windows = a->n_reads = a->n_bases = a->n_batches = 0;
     a->failed = false;
+    a->exchanged = false;
     return DK_OK;
 }
 
@@ -1543,14 +1742,16 @@ dk_status dk_accum_add(dk_accum *a, const dk_reads *r, dk_stats *stats)
     dk_engine *e = a->e;
     CHECK_ARG(e, r->e == e);
     if (a->failed) return fail(e, DK_ERR_OVERFLOW, "the accumulator lost records in an earlier call: dk_accum_reset it first");
+    if (a->exchanged) return fail(e, DK_ERR_INVALID_ARG, "the accumulator was consumed by dk_accum_exchange_finish: dk_accum_reset it first");
     DK_HIP(e, hipSetDevice(e->device));
+    DK_TRY(reads_ready(e, r));
     DK_HIP(e, hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream));
     memset(e->h_ctr, 0, sizeof(Counters));
     stage_begin(e);
     dk_status st = DK_OK;
     if (r->n_bases) {
-        bool direct = e->cfg.mode == DK_MODE_DIRECT ||
-                      (e->cfg.mode == DK_MODE_AUTO && (a->s ? !dk::bucketed_pays(e, r->n_bases, a->wbits) : r->n_bases < (1ULL << 22)));
+        bool direct = mode_of(e) == DK_MODE_DIRECT ||
+                      (mode_of(e) == DK_MODE_AUTO && (a->s ? !dk::bucketed_pays(e, r->n_bases, a->wbits) : r->n_bases < (1ULL << 22)));
         uint64_t redo_from = 0, absent_done = 0;
         if (!direct) {
             bool fatal = false;
@@ -1603,6 +1804,7 @@ dk_status dk_accum_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_s
     CHECK_ARG(e, out != nullptr && min_count >= 1);
     *out = nullptr;
     if (a->failed) return fail(e, DK_ERR_OVERFLOW, "the accumulator lost records in an earlier call: dk_accum_reset it first");
+    if (a->exchanged) return fail(e, DK_ERR_INVALID_ARG, "the accumulator was consumed by dk_accum_exchange_finish: dk_accum_reset it first");
     DK_HIP(e, hipSetDevice(e->device));
     dk_result *res = result_new(e);
     if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
@@ -1642,6 +1844,7 @@ dk_status dk_accum_device_view(dk_accum *a, void **d_store, void **d_fill, void 
     if (!a) return DK_ERR_INVALID_ARG;
     dk_engine *e = a->e;
     if (a->failed) return fail(e, DK_ERR_OVERFLOW, "the accumulator lost records in an earlier call: dk_accum_reset it first");
+    if (a->exchanged) return fail(e, DK_ERR_INVALID_ARG, "the accumulator was consumed by dk_accum_exchange_finish: dk_accum_reset it first");
     DK_HIP(e, hipSetDevice(e->device));
     unsigned long long n = 0;
     DK_HIP(e, hipMemcpyAsync(&n, a->d_novf, 8, hipMemcpyDeviceToHost, e->stream));
@@ -1686,6 +1889,140 @@ dk_status dk_accum_finish_pieces(dk_accum *a, const void *d_stores, const void *
         stats->n_emitted = res->n;
     }
     *out = res;
+    return DK_OK;
+}
+
+// Multi-GPU end of a child pass behind the C ABI: every rank has accumulated ITS child reads over
+// the same hash window; the ranks swap unit ranges on the engine's communicator -- in place, piece by piece through the
+// staging buffer, so no second copy of the store exists -- and each rank counts its own share of the units from the P
+// pieces.  Collective: every rank of the communicator must call it.
+dk_status dk_accum_exchange_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_stats *stats, uint64_t *bytes_sent)
+{
+    if (!a) return DK_ERR_INVALID_ARG;
+    dk_engine *e = a->e;
+    CHECK_ARG(e, out != nullptr && min_count >= 1);
+    *out = nullptr;
+    if (bytes_sent) *bytes_sent = 0;
+    dk_comm *c = e->comm;
+    if (c && c->dead) return fail(e, DK_ERR_HIP, "the communicator was aborted by an earlier failure");
+    if (!c || !c->comm) {
+        if (e->cfg.world_size > 1) return fail(e, DK_ERR_INVALID_ARG, "no communicator: dk_comm_init first");
+        return dk_accum_finish(a, min_count, out, stats);
+    }
+    if (a->exchanged) return fail(e, DK_ERR_INVALID_ARG, "the accumulator was consumed by dk_accum_exchange_finish: dk_accum_reset it first");
+    DK_HIP(e, hipSetDevice(e->device));
+    RcclApi *api = rccl();
+    const uint64_t P = c->world, r = c->rank;
+    CHECK_ARG(e, P <= (uint64_t)MAX_R);
+    if (a->n_units % P != 0) return fail(e, DK_ERR_UNSUPPORTED, "%llu counting units do not split over %llu ranks",
+                                         (unsigned long long)a->n_units, (unsigned long long)P);
+    const size_t rb = accum_rec_bytes(a), ob = a->wide ? sizeof(Rec2) : sizeof(Rec1);
+    // 1. one 64-byte header per rank, all-gathered: the ranks must have built their accumulators alike, and a rank whose
+    //    accumulator failed makes every rank return an error here instead of leaving the others inside a collective
+    unsigned long long my_ovf = 0;
+    DK_HIP(e, hipMemcpyAsync(&my_ovf, a->d_novf, 8, hipMemcpyDeviceToHost, e->stream));
+    DK_HIP(e, hipStreamSynchronize(e->stream));
+    if (my_ovf > a->ovf_cap) my_ovf = a->ovf_cap;
+    constexpr int HW = 8;
+    uint64_t hdr[MAX_R * HW] = {0};
+    uint64_t *mine = hdr + r * HW;
+    mine[0] = a->n_units; mine[1] = a->unit_cap; mine[2] = rb; mine[3] = ((uint64_t)a->wbits << 32) | a->widx;
+    mine[4] = a->failed ? 1 : 0; mine[5] = my_ovf;
+    uint64_t *d_hdr = nullptr;
+    DK_TRY(pool_alloc(e, sizeof hdr, (void **)&d_hdr));
+    dk_status st = DK_OK;
+    hipError_t h = hipMemcpyAsync(d_hdr + r * HW, mine, HW * 8, hipMemcpyHostToDevice, e->stream);
+    if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "header upload failed: %s", hipGetErrorString(h));
+    if (st == DK_OK) {
+        const int rr = api->AllGather(d_hdr + r * HW, d_hdr, HW * 8, RCCL_UINT8, c->comm, e->stream);
+        if (rr != RCCL_SUCCESS) st = comm_fail(e, false, "ncclAllGather(header)", rr, __FILE__, __LINE__);
+    }
+    if (st == DK_OK) {
+        h = hipMemcpyAsync(hdr, d_hdr, P * HW * 8, hipMemcpyDeviceToHost, e->stream);
+        if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+        if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "header exchange failed: %s", hipGetErrorString(h));
+    }
+    pool_free(e, d_hdr);
+    if (st != DK_OK) return st;
+    uint64_t ovf_max = 0, ovf_sum = 0;
+    for (uint64_t q = 0; q < P; q++) {
+        const uint64_t *hq = hdr + q * HW;
+        if (hq[4]) return fail(e, DK_ERR_OVERFLOW, "rank %llu's accumulator lost records in an earlier call: every rank stops here",
+                               (unsigned long long)q);
+        if (hq[0] != mine[0] || hq[1] != mine[1] || hq[2] != mine[2] || hq[3] != mine[3])
+            return fail(e, DK_ERR_INVALID_ARG, "accumulators differ between ranks %llu and %llu (units, unit capacity, record size or "
+                        "window): create them with the same capacity and window on every rank", (unsigned long long)r, (unsigned long long)q);
+        ovf_max = std::max(ovf_max, hq[5]);
+        ovf_sum += hq[5];
+    }
+    dk_result *res = result_new(e);
+    if (!res) return fail(e, DK_ERR_OOM, "host allocation failed");
+    h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+    if (h != hipSuccess) { delete res; return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
+    memset(e->h_ctr, 0, sizeof(Counters));
+    stage_begin(e);
+    // 2. fill counters and stores: slice q of mine for slice r of rank q, in place
+    const uint64_t upr = a->n_units / P;
+    uint64_t sent = 0;
+    a->exchanged = true;                          // from here on the store is no longer in unit order
+    st = alltoall_in_place(e, (char *)a->fill, upr * 4, 4, &sent);
+    if (st == DK_OK) st = alltoall_in_place(e, (char *)a->store, upr * (uint64_t)a->unit_cap * rb, 256, &sent);
+    // 3. overflow lists (rare, small): padded all-gather, then packed side by side
+    char *gath = nullptr, *extra = nullptr;
+    if (st == DK_OK && ovf_max) {
+        st = pool_alloc(e, P * ovf_max * ob, (void **)&gath);
+        if (st == DK_OK) st = pool_alloc(e, ovf_sum * ob, (void **)&extra);
+        if (st == DK_OK && my_ovf) {
+            h = hipMemcpyAsync(gath + r * ovf_max * ob, a->ovf, my_ovf * ob, hipMemcpyDeviceToDevice, e->stream);
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow-list copy failed: %s", hipGetErrorString(h));
+        }
+        if (st == DK_OK) {
+            const int rr = api->AllGather(gath + r * ovf_max * ob, gath, ovf_max * ob, RCCL_UINT8, c->comm, e->stream);
+            if (rr != RCCL_SUCCESS) st = comm_fail(e, false, "ncclAllGather(overflow lists)", rr, __FILE__, __LINE__);
+            else sent += (P - 1) * ovf_max * ob;
+        }
+        uint64_t done = 0;
+        for (uint64_t q = 0; q < P && st == DK_OK; q++) {
+            const uint64_t nq = hdr[q * HW + 5];
+            if (!nq) continue;
+            h = hipMemcpyAsync(extra + done * ob, gath + q * ovf_max * ob, nq * ob, hipMemcpyDeviceToDevice, e->stream);
+            if (h != hipSuccess) st = fail(e, DK_ERR_HIP, "overflow-list copy failed: %s", hipGetErrorString(h));
+            done += nq;
+        }
+    }
+    if (st == DK_OK) stage_mark(e, "acc_exchange");
+    // 4. count this rank's share of the units from the P pieces
+    uint64_t n_records = 0;
+    if (st == DK_OK)
+        st = a->wide ? accum_finish_t<true>(e, a, min_count, res, a->store, a->fill, (uint32_t)P, r * upr, upr, extra, ovf_sum, &n_records)
+                     : accum_finish_t<false>(e, a, min_count, res, a->store, a->fill, (uint32_t)P, r * upr, upr, extra, ovf_sum, &n_records);
+    if (st == DK_OK) st = stage_end(e);
+    pool_free(e, gath);
+    pool_free(e, extra);
+    if (st != DK_OK) { dk_result_destroy(res); return st; }
+    if (bytes_sent) *bytes_sent = sent;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->n_reads = a->n_reads;
+        stats->n_bases = a->n_bases;
+        stats->n_windows = a->n_windows;
+        stats->n_valid = a->n_valid;
+        stats->n_absent = n_records;             // the occurrences this rank counted (its share of the hash space, all ranks' reads)
+        stats->n_distinct = e->h_ctr->n_distinct;
+        stats->n_emitted = res->n;
+    }
+    *out = res;
+    return DK_OK;
+}
+
+// host-only arithmetic of the exchanges, exported so that it can be checked without a GPU (tests/test_abi.py)
+dk_status dk_comm_layout(uint64_t staging_bytes, uint64_t slice_bytes, uint32_t rank, uint32_t world_size, uint64_t granule,
+                         uint64_t *piece_bytes, uint64_t *staging_slot)
+{
+    if (world_size < 1 || rank >= world_size || granule == 0 || !piece_bytes || !staging_slot) return DK_ERR_INVALID_ARG;
+    *piece_bytes = exchange_piece_bytes(staging_bytes, slice_bytes, world_size, granule);
+    for (uint32_t q = 0; q < world_size; q++)
+        staging_slot[q] = q == rank && world_size > 1 ? ~0ULL : staging_index(q, rank, world_size);
     return DK_OK;
 }
 

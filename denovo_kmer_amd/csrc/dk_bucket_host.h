@@ -130,7 +130,11 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     // expected piece size from the largest share a producer can get (tiles are dealt round-robin,
     // so shares differ by at most one tile)
     const uint64_t tiles_per_wg = (n_tiles + p->G - 1) / p->G;
-    const double share1 = std::min((double)p->n_max, (double)(tiles_per_wg * (uint64_t)p->tile) / (double)(1ULL << wbits));
+    // (a tile of positions holds n_windows / n_bases windows on average: 120 / 151 for 150-bp reads and k = 31 -- sizing
+    // the pieces by positions cost 26 % more level-1 room than the records need; batches whose read lengths differ a lot
+    // between tiles lean on the 8 sigma and on the overflow list)
+    const double win_frac = r->n_bases ? std::min(1.0, 1.02 * (double)n_all / (double)r->n_bases) : 1.0;
+    const double share1 = std::min((double)p->n_max, (double)(tiles_per_wg * (uint64_t)p->tile) * win_frac / (double)(1ULL << wbits));
     const double m1 = share1 / (double)p->p1;
     const double m2 = (double)p->n_max / (double)p->n_seg;
     if (m1 * 2 + 1e6 >= 4.0e9 || m2 * 2 + 1e6 >= 4.0e9) return false;    // u32 cursors
@@ -242,6 +246,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
                                     bool need_scratch = true)
 {
     using R = typename RecOf<WIDE>::type;
+    e->plan = dk_plan_info{p.b3 ? 3 : 2, p.b1, p.b2, p.b3, p.sbits, (int)p.slabs, p.variant, p.T};
     const uint64_t seg_recs = p.n_seg / p.slabs * (uint64_t)p.cap2;
     // 128 bytes between the pieces of consecutive level-1 bins: a workgroup of scan_part writes to 2^b1 frontiers that are
     // G * capw records apart, always a multiple of 4 KiB, so all of them sat on the same few HBM channels at any moment
@@ -264,7 +269,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     B.rec = p.b3 ? B.a : B.b;
     B.scratch = p.b3 ? B.b : B.a;
     if (n_coarse) DK_HIP(e, hipMemsetAsync(B.cursorA, 0, n_coarse * 4, e->stream));
-    B.ovf_cap = e->opt.ovf_cap > 0 ? (uint64_t)e->opt.ovf_cap : std::max<uint64_t>(1ULL << 20, p.n_max / 8);
+    B.ovf_cap = e->opt.ovf_cap > 0 ? (uint64_t)e->opt.ovf_cap : std::max<uint64_t>(1ULL << 20, p.n_max / (p.n_max >> 30 ? 16 : 8));
     DK_TRY(pool_alloc(e, B.ovf_cap * sizeof(R), (void **)&B.ovf));
     DK_HIP(e, hipMemsetAsync(B.cursor2, 0, p.n_seg * 4, e->stream));
     const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
@@ -432,7 +437,7 @@ inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &
 // (unit_base + local index), n_absent records in all, extra_room more entries per region.
 // The table is sized for every record being distinct when min_count == 1.  With min_count > 1 few records
 // survive (a whole-genome child keeps ~1.5 % of its absent occurrences at min_count 2): the table is then sized for
-// an eighth of the upper bound n_absent / min_count, and if a region runs out the kernel has still tallied what
+// a sixteenth of the upper bound n_absent / min_count, and if a region runs out the kernel has still tallied what
 // each region needs (region_fill), so the count is redone once with exactly that much room.
 template <bool WIDE>
 inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename RecOf<WIDE>::type> &list, uint64_t n_units,
@@ -473,7 +478,8 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
     const uint64_t used_regions = std::min<uint64_t>(RESULT_REGIONS, n_units);
     // size_records (accumulators: their capacity): the optimistic table is sized from it instead of from n_absent, so that
     // every counting pass of one accumulator asks the pool for the same block and none of them waits for hipMalloc
-    const uint64_t bound = min_count > 1 ? std::max(n_absent, size_records) / min_count / 8 : n_absent;
+    // (a whole-genome child keeps 1.5 % of its absent occurrences at min_count 2: a sixteenth of the bound is 2.4 times that)
+    const uint64_t bound = min_count > 1 ? std::max(n_absent, size_records) / min_count / 16 : n_absent;
     uint64_t region_cap = bound / used_regions + bound / (8 * used_regions) + 65536 + extra_room;
     dk_status st = DK_OK;
     for (int attempt = 0; attempt < 2; attempt++) {

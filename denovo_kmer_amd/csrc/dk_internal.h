@@ -14,6 +14,23 @@ struct dk_pool_block {
     bool in_use;
 };
 
+// An arena (dk_engine_reserve): one hipMalloc made ahead of time, carved up first by best fit; neighbouring free
+// segments coalesce, so a workspace of any shape finds room as long as the bytes are there.
+struct dk_arena_seg {
+    size_t off, bytes;
+    bool in_use;
+};
+struct dk_arena {
+    char *base;
+    size_t bytes;
+    std::vector<dk_arena_seg> segs;       // sorted by offset, covering [0, bytes)
+};
+
+// what the last bucketed operation planned (dk_engine_get_info)
+struct dk_plan_info {
+    int levels = 0, b1 = 0, b2 = 0, b3 = 0, sbits = 0, slabs = 0, scan_variant = 0, T = 0;
+};
+
 // Run-time options of an engine (dk_engine_set_option): the capacity hint is for callers, the rest are the
 // test hooks that force a kernel geometry on inputs too small to select it (validated; 0 = automatic).
 struct dk_options {
@@ -31,6 +48,7 @@ struct dk_options {
     int slab_mb = 0;              // automatic slabs: room for one slab's regions in MiB (default 1024)
     int ovf_cap = 0;              // capacity of the partition's overflow list in records (test hook; 0 = an eighth of the batch)
     int accum_min_u = 0;          // dk_accum_create: at least 2^n counting units per segment (test hook: packed units on small sets)
+    int mode = 0;                 // kernel family override: 0 = dk_config.mode, 1 = direct, 2 = bucketed
     int accum_plain = 0;          // dk_accum_create: 1 = never use packed 6-byte unit records (A/B runs, tests)
     int scan_bits = 0;            // scan_part: most hash bits level 1 may take (default 10; 9 = round 2's limit, for A/B runs)
     int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
@@ -52,10 +70,15 @@ struct dk_engine {
     int n_cu;
     hipStream_t stream;
     bool own_stream;
+    hipStream_t copy_stream = nullptr;    // uploads of dk_reads_from_packed_async (created on first use)
+    hipEvent_t copy_ev = nullptr;         // orders an upload behind the work already queued on `stream`
     std::string err;
     dk::Counters *d_ctr;          // device counters of the running operation
     dk::Counters *h_ctr;          // pinned host mirror
     std::vector<dk_pool_block> pool;
+    std::vector<dk_arena> arenas;
+    dk_plan_info plan;
+    uint64_t pool_peak = 0;       // most bytes ever handed out at one time
     // stage timing of the last operation
     // (a slab-wise operation marks two stages per slab: the marks are summed by name into the dk_timings entries)
     hipEvent_t ev[DK_MAX_MARKS + 1];
@@ -70,6 +93,7 @@ struct dk_reads {
     uint64_t *d_mask;
     uint64_t n_bases, n_reads, n_windows;
     bool owns;
+    hipEvent_t ready = nullptr;   // dk_reads_from_packed_async: the upload's completion on the copy stream
 };
 
 struct dk_set {
@@ -99,6 +123,7 @@ struct dk_accum {
     uint64_t n_absent, n_valid, n_windows, n_reads, n_bases, n_batches;
     bool wide;
     bool packed;                  // units hold 6-byte packed records (k <= 32 and T + u >= 16; dk_bucket_seg.h)
+    bool exchanged;               // dk_accum_exchange_finish transposed the store in place: reset before reuse
     bool failed;                  // a batch lost records (overflow list full) or died half-way: reset before reuse
 };
 

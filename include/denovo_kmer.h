@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DK_ABI_VERSION 2
+#define DK_ABI_VERSION 3
 
 typedef int32_t dk_status;
 enum {
@@ -132,12 +132,26 @@ dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
  *   "scan_variant" 1..6, "repart_variant" 0..1, "force_l3" 0..1, "b1_up" -4..4, "count_seg" >= 64, "cnt_mid" >= 1,
  *   "sub_split" 0..3 | 9 (0 = automatic, 9 = never), "repart_plain" 0..1, "merge_pass_bits" 0..8, "merge_idx64" 0..1,
  *   "sink_plain" 0..1 (1: dk_probe never routes absent records into finer counting units while probing),
- *   "accum_unit_cap" records per counting unit of the next dk_accum_create, used when it is at least what the capacity needs */
+ *   "accum_unit_cap" records per counting unit of the next dk_accum_create, used when it is at least what the capacity needs,
+ *   "scan_bits" 0 | 1..10 (most hash bits level 1 takes; 9 = round 2's layout), "slabs" 0..1024 (slab-wise level 2 of
+ *   insert / accumulate: number of slabs, 0 = automatic from "slab_mb", the room of one slab's regions in MiB),
+ *   "ovf_cap" capacity of the partition's overflow list in records, "accum_plain" 0..1 (1: 8-byte accumulator records
+ *   even where 6-byte packed ones apply), "accum_min_u" 0..10 (at least 2^n counting units per segment),
+ *   "mode" 0..2 (kernel family override: 0 = dk_config.mode, 1 = direct, 2 = bucketed) */
 dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
+/* What the engine did / holds, by name: "plan_levels", "plan_b1", "plan_b2", "plan_b3", "plan_sbits", "plan_slabs",
+ * "plan_scan_variant", "plan_segment_bits" (the partition plan of the last bucketed operation), "pool_bytes_in_use",
+ * "pool_bytes_cached", "pool_bytes_reserved", "pool_bytes_peak" (device memory).  Unknown name: DK_ERR_INVALID_ARG. */
+dk_status   dk_engine_get_info(const dk_engine *e, const char *name, int64_t *value);
 /* The engine keeps the device memory of finished operations in a pool for the next one (no allocation inside timed
  * work); it hands cached blocks back by itself when an allocation fails.  dk_engine_trim frees every cached block now --
  * between the parent build and the child pass of a whole-genome run, whose workspaces differ -- and reports the bytes freed. */
 dk_status   dk_engine_trim(dk_engine *e, uint64_t *bytes_freed);
+/* Allocate `bytes` of device memory now, as one arena that every later workspace, read batch, set and accumulator of the
+ * engine is carved from (best fit, free neighbours coalesce): the one slow hipMalloc of a whole-genome run (seconds for
+ * 150 GB) then happens where the host chooses -- while it opens its input files -- instead of inside the first batch.
+ * May be called more than once (one more arena each).  bytes = 0: hand back every arena nothing lives in. */
+dk_status   dk_engine_reserve(dk_engine *e, uint64_t bytes);
 
 /* ---- read batches (replaces: the &[u8] read sequences handed to kmer.rs by the BAM loop) --- */
 /* ASCII reads, concatenated, offsets[n_reads+1]; packed on the GPU */
@@ -146,6 +160,15 @@ dk_status dk_reads_from_ascii(dk_engine *e, const uint8_t *seq, const uint64_t *
 /* host buffers already in the packed format above (copied to the device) */
 dk_status dk_reads_from_packed(dk_engine *e, const uint64_t *bases, const uint64_t *mask,
                                uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out);
+/* Overlapped ingest: as dk_reads_from_packed, but the copies run on the engine's copy stream and the call returns at
+ * once; whatever consumes the batch (dk_set_insert, dk_probe, dk_accum_add, ...) waits for them on the device, so batch
+ * i + 1 crosses PCIe while batch i is being worked on.  bases / mask must stay valid and unchanged until dk_reads_wait
+ * returns, and should be pinned host memory (dk_host_alloc): pageable memory makes the call block. */
+dk_status dk_reads_from_packed_async(dk_engine *e, const uint64_t *bases, const uint64_t *mask,
+                                     uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out);
+dk_status dk_reads_wait(dk_reads *r);                           /* blocks until the upload of r has finished */
+dk_status dk_host_alloc(uint64_t bytes, void **out);            /* pinned host memory for the async upload */
+void      dk_host_free(void *p);
 /* device buffers already in the packed format (borrowed, not copied, not freed) */
 dk_status dk_reads_attach_device(dk_engine *e, const void *d_bases, const void *d_mask,
                                  uint64_t n_bases, uint64_t n_reads, uint64_t n_windows, dk_reads **out);
@@ -214,6 +237,11 @@ dk_status dk_comm_unique_id(uint8_t *id /* DK_COMM_ID_BYTES */);
 dk_status dk_comm_init(dk_engine *e, const uint8_t *id /* DK_COMM_ID_BYTES */, uint32_t rank, uint32_t world_size);
 dk_status dk_comm_finalize(dk_engine *e);
 dk_status dk_set_allreduce_or(dk_set *s, uint64_t *bytes_sent);
+/* host-only arithmetic of the piece-wise exchanges (no GPU needed; tests): with `staging_bytes` of staging, slices of
+ * slice_bytes and pieces that are multiples of `granule`, the bytes one piece carries and, for every peer q of `rank`,
+ * the index of q's piece in the staging buffer (~0 for the rank itself when world_size > 1) */
+dk_status dk_comm_layout(uint64_t staging_bytes, uint64_t slice_bytes, uint32_t rank, uint32_t world_size, uint64_t granule,
+                         uint64_t *piece_bytes, uint64_t *staging_slot /* world_size entries */);
 
 /* ---- membership pass + KmerCounter (replaces: child loop of counter.rs) ---------------------- */
 /* probe every window of r against s; absent k-mers are counted.  s == NULL counts every k-mer
@@ -239,14 +267,15 @@ void      dk_result_destroy(dk_result *res);
  * loop of counter.rs keeps across the whole BAM) -----------------------------------------------------------------
  * dk_probe returns the table of ONE batch; summing per-batch tables does not scale to a whole genome (a 30x child
  * leaves ~2 x 10^10 absent k-mer occurrences, nearly all distinct).  An accumulator keeps the absent occurrences
- * themselves -- 8-byte bucket records (16 for k > 32) grouped by hash prefix -- across any number of dk_accum_add
+ * themselves -- 6- or 8-byte bucket records (16 for k > 32) grouped by hash prefix -- across any number of dk_accum_add
  * calls and counts each group once in dk_accum_finish, so counts and the min_count threshold are exact over the
  * whole sample.  When the records of the whole hash space do not fit beside the set, the sample is streamed
  * window_count times (a power of two): pass w keeps only the k-mers whose hash falls into the w-th of window_count
  * equal ranges; every pass touches 1/window_count of the set and of the partition workspace, and the union of the
  * passes' tables is the whole result (the ranges are disjoint).
  *   capacity_records  expected number of absent occurrences per pass (slack for the spread between groups is added
- *                     inside: the store takes ~1.1 x 8 bytes x capacity); occurrences beyond a group's room go to
+ *                     inside: the store takes ~1.1 x record bytes x capacity -- 6 bytes where the groups' common hash
+ *                     prefix covers 16 bits or more, i.e. sets from 2^28 bits up, see dk_accum_geometry); occurrences beyond a group's room go to
  *                     an overflow list of capacity/64 entries, and DK_ERR_OVERFLOW is returned once that is full
  *                     (the accumulator is then unusable until dk_accum_reset; use more windows or a larger capacity)
  *   s == NULL         every k-mer counts (KmerCounter over a sample in batches) */
@@ -278,6 +307,13 @@ dk_status dk_accum_device_view(dk_accum *a, void **d_store, void **d_fill, void 
 dk_status dk_accum_finish_pieces(dk_accum *a, const void *d_stores, const void *d_fills, uint32_t n_pieces,
                                  uint64_t first_unit, uint64_t n_units, const void *d_extra, uint64_t n_extra,
                                  uint32_t min_count, dk_result **out, dk_stats *stats);
+/* The same exchange + counting behind the C ABI, on the engine's communicator (dk_comm_init): collective.  The ranks
+ * first compare accumulator geometry and state (a rank whose accumulator failed makes EVERY rank return an error, no
+ * rank is left waiting), then swap unit ranges IN PLACE, piece by piece through the communicator's staging buffer
+ * (grouped ncclSend / ncclRecv; no second copy of the store), all-gather the overflow lists, and each rank counts its
+ * share of the units from the P pieces.  Afterwards the accumulator is consumed: dk_accum_reset before reuse.  Without a
+ * communicator (one rank) it is dk_accum_finish.  stats->n_absent = occurrences this rank counted.  bytes_sent may be NULL. */
+dk_status dk_accum_exchange_finish(dk_accum *a, uint32_t min_count, dk_result **out, dk_stats *stats, uint64_t *bytes_sent);
 /* bytes of device memory the accumulator holds */
 dk_status dk_accum_device_bytes(const dk_accum *a, uint64_t *n_bytes);
 void      dk_accum_destroy(dk_accum *a);

@@ -66,6 +66,15 @@ public:
     Engine &operator=(const Engine &) = delete;
     dk_engine *get() const { return e_; }
     uint32_t k() const { return k_; }
+    // one arena for everything the engine allocates later (the slow hipMalloc happens here, not inside the first batch)
+    void reserve(uint64_t bytes) { check(dk_engine_reserve(e_, bytes), e_); }
+    void set_option(const char *name, int64_t value) { check(dk_engine_set_option(e_, name, value), e_); }
+    int64_t info(const char *name) const
+    {
+        int64_t v = 0;
+        check(dk_engine_get_info(e_, name, &v), e_);
+        return v;
+    }
 
 private:
     dk_engine *e_ = nullptr;
@@ -233,12 +242,13 @@ public:
         return st;
     }
     void reset(uint32_t window_index) { check(dk_accum_reset(a_, window_index), e_.get()); }
-    // appends the window's table to `out` (k-mers of different windows are disjoint)
-    void finish(uint32_t min_count, KmerCounts &out)
+    // appends the window's table to `out` (k-mers of different windows are disjoint).  exchange = true (multi-GPU, collective,
+    // after dk_comm_init on the engine): the ranks swap unit ranges first and `out` receives this rank's share of the hash space
+    void finish(uint32_t min_count, KmerCounts &out, bool exchange = false)
     {
         dk_result *res = nullptr;
         dk_stats st;
-        check(dk_accum_finish(a_, min_count, &res, &st), e_.get());
+        check(exchange ? dk_accum_exchange_finish(a_, min_count, &res, &st, nullptr) : dk_accum_finish(a_, min_count, &res, &st), e_.get());
         uint64_t n = 0;
         dk_status rc = dk_result_size(res, &n);
         const size_t at = out.lo.size();

@@ -135,3 +135,27 @@ def test_malformed_read_batches_are_rejected():
         att = d.ReadBatch.attach_device(eng, tb.data_ptr(), tm2.data_ptr(), n, 1, 8, keepalive=(tb, tm2))
         ks = d.KmerSet(eng)
         assert ks.insert_reads(att)["n_valid"] == 8
+
+
+def test_exchange_layout_arithmetic_for_two_to_eight_ranks():
+    """dk_comm_layout is the host-side arithmetic of the native piece-wise exchanges (dk_set_allreduce_or,
+    dk_accum_exchange_finish): for every rank of P = 1..8 the peers' pieces must fill distinct staging slots 0..P-2 in
+    rank order (the order torch's all_to_all_single delivers them in, own slice left out), a piece must be a whole number
+    of granules that fits the staging buffer P - 1 times, and the pieces must tile the slice."""
+    lib = _lib.load()
+    for world in range(1, 9):
+        for rank in range(world):
+            for staging, sl, gran in ((1 << 30, 8 << 30, 65536), (1 << 20, 12345 * 6, 256), (4096, 100, 4), (1 << 30, 1 << 20, 65536)):
+                piece = C.c_uint64()
+                slots = (C.c_uint64 * world)()
+                assert lib.dk_comm_layout(staging, sl, rank, world, gran, C.byref(piece), slots) == 0
+                peers = [q for q in range(world) if q != rank] or [0]
+                got = [int(slots[q]) for q in peers]
+                assert got == list(range(len(peers))), (world, rank, got)
+                if world > 1:
+                    assert int(slots[rank]) == 2**64 - 1
+                p = int(piece.value)
+                assert p > 0 and p * len(peers) <= staging and (p % gran == 0 or p == sl) and p <= sl
+                # the pieces tile the slice: ceil(sl / p) groups, the last one shorter
+                assert sum(min(p, sl - off) for off in range(0, sl, p)) == sl
+    assert lib.dk_comm_layout(1 << 20, 1 << 20, 3, 2, 4, C.byref(piece), slots) != 0     # rank outside the world

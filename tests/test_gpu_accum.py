@@ -324,7 +324,7 @@ def test_many_batches_against_a_2_to_the_36_bit_filter():
 
 
 def test_min_count_table_too_small_is_recounted_exactly():
-    """with min_count > 1 the result table is sized for an eighth of the upper bound; a sample where nearly every
+    """with min_count > 1 the result table is sized for a sixteenth of the upper bound; a sample where nearly every
     k-mer passes the threshold overruns it and is counted a second time with the room the first run tallied"""
     d = dk()
     rng = np.random.default_rng(8)

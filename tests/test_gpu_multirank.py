@@ -295,3 +295,50 @@ def test_native_rccl_allreduce_with_one_rank_as_its_own_peer(set_kind, bits):
         res.close()
         eng.comm_finalize()
         ks.close()
+
+
+@pytest.mark.parametrize("k,min_u,plain", [(31, 8, 0), (31, 0, 0), (45, 0, 0), (31, 8, 1)])
+def test_native_accumulator_exchange_with_one_rank_as_its_own_peer(k, min_u, plain):
+    """dk_accum_exchange_finish on a one-rank RCCL communicator: the header all-gather, the in-place all-to-all of fills
+    and store (slice 0 goes through ncclSend / ncclRecv into the staging buffer and is copied back over itself) and the
+    all-gather of the overflow list all run on the engine's stream, and counting from the exchanged store must give what
+    dk_accum_finish gave before -- packed 6-byte units, plain 8-byte ones and 16-byte ones.  The accumulator is consumed
+    afterwards.  Two GPUs and more are the driver's run (N > 1 remains unverified on hardware)."""
+    import denovo_kmer_amd as d
+    rng = np.random.default_rng(21)
+    alphabet = np.array(list("ACGT"))
+    parents = ["".join(alphabet[rng.integers(0, 4, size=150)]) for _ in range(300)]
+    child = ["".join(alphabet[rng.integers(0, 4, size=150)]) for _ in range(1500)] + parents[:100]
+    child = child + child[:400]
+    with d.Engine(k=k, filter_log2_bits=27, n_hashes=4, seed=11, mode="bucketed") as eng:
+        eng.set_option("accum_min_u", min_u)
+        eng.set_option("accum_plain", plain)
+        ks = d.KmerSet(eng)
+        ks.insert_sequences(parents)
+        # a capacity far below the sample: most units run full, the overflow list is exchanged too
+        acc = d.ChildAccumulator(eng, ks, capacity_records=60_000 if min_u else 3_000_000)
+        for part in (child[:700], child[700:]):
+            acc.add(d.ReadBatch.from_sequences(eng, part))
+        ref = acc.finish(min_count=2)
+        rhi, rlo, rcnt = ref.to_host()
+        assert len(rlo) > 0 and int(rcnt.max()) >= 2
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        got = acc.exchange_finish(min_count=2)
+        ghi, glo, gcnt = got.to_host()
+        assert np.array_equal(glo, rlo) and np.array_equal(ghi, rhi) and np.array_equal(gcnt, rcnt)
+        assert got.stats["n_absent"] == ref.stats["n_absent"] and got.stats["n_distinct"] == ref.stats["n_distinct"]
+        assert got.bytes_sent > 0
+        assert "acc_exchange" in [n for n, _ in eng.timings()["stages"]]
+        with pytest.raises(d.DkError):                 # consumed: the store is no longer in unit order
+            acc.add(d.ReadBatch.from_sequences(eng, child[:10]))
+        with pytest.raises(d.DkError):
+            acc.finish()
+        acc.reset(0)
+        acc.add(d.ReadBatch.from_sequences(eng, child[:700]))
+        again = acc.exchange_finish(min_count=1)
+        assert len(again) > 0
+        for r in (ref, got, again):
+            r.close()
+        eng.comm_finalize()
+        acc.close()
+        ks.close()
