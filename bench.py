@@ -7,13 +7,16 @@ Workloads (BASELINE.json `configs`):
   wgs   (default) configs[2]: k=31, full 30x whole-genome trio, ~1.2 B synthetic 150-bp reads per sample on one
         MI355X.  The parents are inserted batch by batch into a 2^39-bit (64 GiB) Bloom filter resident in HBM
         (reported under "parent_build"); the child is streamed in batches through dk_accum_add, which keeps the
-        absent k-mer occurrences on the GPU so that counts and min_count are exact over the whole sample.  The
-        occurrences of the whole hash space do not fit beside the filter, so the child is streamed in
-        `hash_windows` passes, each covering 1/hash_windows of the hash space (and of the filter).
+        absent k-mer occurrences on the GPU so that counts and min_count are exact over the whole sample.  With
+        6-byte packed accumulator records and the slab-wise partition (one scan per batch, level 2 slab by slab)
+        the occurrences of the whole hash space fit beside the filter: ONE pass over the child (`hash_windows` 1;
+        --windows 2 restores round 2's two passes, each covering half of the hash space and of the filter).
         A "step" = one child batch through one pass; it completes 1/hash_windows of the batch's membership work,
-        so `value` counts n_windows / hash_windows per step.  The K timed steps end with the counting of what they
-        accumulated (dk_accum_finish) inside the timed region.  After the timed steps the whole child is run end
-        to end (all passes, all batches, finish) and reported under "end_to_end".
+        so `value` counts n_windows / hash_windows per step.  The steps walk the resident batches; whenever every
+        resident batch has been added once, and after the last step, what was accumulated is counted
+        (dk_accum_finish) inside the timed region.  After the timed steps the whole child is run end
+        to end (all passes, all batches, finish) and reported under "end_to_end", and -- N = 1 -- the other two
+        single-GPU workloads run a few steps each and are attached under "other_workloads".
   chr20 configs[1]: k=31, chr20-scale 30x trio = 12.8 M reads per sample per GPU, 2^34-bit filter; a step is one
         dk_probe call over the resident child batch (round 1's headline).
   ont   configs[4]: k=51, 10-kb reads with 5 % errors, 192 k reads per sample, 2^35-bit filter; step as chr20.
@@ -36,8 +39,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 XGMI_LINK_GBS = 153.0          # per link, 7 links per GPU
 
 WORKLOADS = {
-    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=32_000_000, parent_batch=64_000_000, log2_bits=39, err=5e-3,
-                min_count=2, windows=2, cfg="configs[2]"),
+    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=48_000_000, parent_batch=128_000_000, log2_bits=39, err=5e-3,
+                min_count=2, windows=1, cfg="configs[2]"),
     "chr20": dict(k=31, read_len=150, reads=12_800_000, batch=12_800_000, parent_batch=12_800_000, log2_bits=34, err=5e-3,
                   min_count=1, windows=1, cfg="configs[1]"),
     "ont": dict(k=51, read_len=10_000, reads=192_000, batch=192_000, parent_batch=192_000, log2_bits=35, err=5e-2, min_count=1,
@@ -118,10 +121,12 @@ def committed_traffic(workload, reads, log2_bits, world):
     return None, None
 
 
-def cpu_baseline(dk, eng, kset, gcfg, args, wl, sample_reads):
+def cpu_baseline(dk, eng, kset, gcfg, args, wl, sample_reads, accum_windows=0, slabs=0):
     """Time the CPU oracle ("port": the build's C restatement, OpenMP over reads on the host cores
     this process may use) on a bounded sample of the same child workload against the same filter,
-    and cross-check the GPU on that sample."""
+    and cross-check the GPU on that sample.  accum_windows > 0 (wgs): the sample goes through the path that produced
+    `value` -- dk_accum_add with the bucketed family forced (a sample this small would take the direct family in AUTO
+    mode), the same number of level-2 slabs, packed accumulator units, every hash window, then dk_accum_finish."""
     import numpy as np
     from oracle import orc
     filt = kset.to_host()
@@ -136,10 +141,34 @@ def cpu_baseline(dk, eng, kset, gcfg, args, wl, sample_reads):
                                  min_count=1, n_threads=cores)
     dt = time.perf_counter() - t0
     t_probe, t_sort, t_merge = orc.last_phase_seconds()
-    res = dk.KmerCounter(eng).child_only(sb, kset)
-    hi, lo, cnt = res.to_host()
+    if accum_windows:
+        eng.set_option("mode", 2)
+        eng.set_option("slabs", slabs)
+        acc = dk.ChildAccumulator(eng, kset, capacity_records=int(1.3 * st["n_absent"] / accum_windows) + 4096,
+                                  window_count=accum_windows)
+        his, los, cnts, path = [], [], [], []
+        for w in range(accum_windows):
+            acc.reset(w)
+            acc.add(sb)
+            path = [n for n, _ in eng.timings()["stages"]] + ["slabs=%d" % eng.info("plan_slabs"), "record_bytes=%d" % acc.geometry()[2]]
+            r = acc.finish(min_count=1)
+            h, l, c = r.to_host(sort=False)
+            his.append(h)
+            los.append(l)
+            cnts.append(c)
+            r.close()
+        acc.close()
+        eng.set_option("mode", 0)
+        eng.set_option("slabs", 0)
+        hi, lo, cnt = np.concatenate(his), np.concatenate(los), np.concatenate(cnts)
+        order = np.lexsort((lo, hi))
+        hi, lo, cnt = hi[order], lo[order], cnt[order]
+    else:
+        res = dk.KmerCounter(eng).child_only(sb, kset)
+        path = [n for n, _ in eng.timings()["stages"]]
+        hi, lo, cnt = res.to_host()
+        res.close()
     ok = bool(np.array_equal(lo, km["lo"]) and np.array_equal(hi, km["hi"]) and np.array_equal(cnt, cn))
-    res.close()
     sb.close()
     del filt
     return {"value": st["n_windows"] / t_probe / 1e9, "unit": "Gk-mers/s", "cores": cores, "kind": "port",
@@ -149,7 +178,7 @@ def cpu_baseline(dk, eng, kset, gcfg, args, wl, sample_reads):
                       f"{t_sort:.1f} s (parallel sort) + {t_merge:.1f} s (serial merge) more, {dt:.1f} s for the whole call",
             "probe_seconds": t_probe, "sort_seconds": t_sort, "merge_seconds": t_merge, "whole_call_seconds": dt,
             "value_including_counting": st["n_windows"] / dt / 1e9,
-            "gpu_matches_oracle_on_sample": ok}
+            "gpu_matches_oracle_on_sample": ok, "gpu_path_of_the_sample": path}
 
 
 T_START = time.perf_counter()
@@ -158,6 +187,55 @@ T_START = time.perf_counter()
 def progress(msg):
     """phase marks on stderr (a full-genome run is silent for minutes otherwise)"""
     print("[bench %7.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+def run_probe_workload(dk, torch, name, args, steps, warmup):
+    """One of the single-GPU probe workloads (chr20 = configs[1], ont = configs[4]) on cuda:0 with an engine of its own:
+    parents inserted, the child resident in HBM, `warmup` + `steps` dk_probe calls timed as the default run times its
+    steps.  -> the entry bench.py attaches under "other_workloads" when the default (wgs) run has finished."""
+    wl = WORKLOADS[name]
+    k, L, reads = wl["k"], wl["read_len"], wl["reads"]
+    rec_bytes = 16 if k > 32 else 8
+    genome_len = max(reads * L // 30, 4 * L)
+    gcfg = dk.synth_config(seed=args.seed, genome_len=genome_len, read_len=L, err_rate=wl["err"])
+    filter_bytes = (1 << wl["log2_bits"]) // 8
+    with dk.Engine(k=k, filter_log2_bits=wl["log2_bits"], n_hashes=args.n_hashes, seed=args.seed, device_id=torch.cuda.current_device(),
+                   mode=args.mode) as eng:
+        kset = dk.KmerSet(eng)
+        insert = {}
+        for smp in (0, 1):
+            pb = dk.ReadBatch.synth(eng, gcfg, smp, 0, reads)
+            ist = kset.insert_reads(pb)
+            t = eng.timings()
+            insert = {"ms": t["total_ms"], "stages_ms": {n: ms for n, ms in t["stages"]}, "gkmers_s": ist["n_windows"] / (t["total_ms"] * 1e-3) / 1e9}
+            pb.close()
+        child = dk.ReadBatch.synth(eng, gcfg, 2, 0, reads)
+        counter = dk.KmerCounter(eng)
+        for _ in range(warmup):
+            counter.child_only(child, kset).close()
+        torch.cuda.synchronize()
+        stage_sum, windows, st = {}, 0, None
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = counter.child_only(child, kset)
+            st = r.stats
+            windows += st["n_windows"]
+            for n, ms in eng.timings()["stages"]:
+                stage_sum[n] = stage_sum.get(n, 0.0) + ms
+            r.close()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        stages = {n: ms / steps for n, ms in stage_sum.items()}
+        sb = {n: stage_algorithmic_bytes(n, st, filter_bytes, rec_bytes, 1) for n in stages}
+        traffic, tsrc = committed_traffic(name, reads, wl["log2_bits"], 1)
+        out = {"config": "%s: k=%d, %d x %d bp reads per sample, parent Bloom 2^%d bits, min_count %d"
+                         % (wl["cfg"], k, reads, L, wl["log2_bits"], wl["min_count"]),
+               "value": windows / elapsed / 1e9, "unit": "Gk-mers/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": elapsed / steps * 1e3, "stages_ms": stages, "roofline": roofline_of(stages, sb, traffic, tsrc),
+               "pass_stats": st, "parent_insert": insert}
+        child.close()
+        kset.close()
+    return out
 
 
 def main():
@@ -182,6 +260,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline; 0 = min(cores this process may use, 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="wgs: skip the full child run after the timed steps")
+    ap.add_argument("--no-reserve", action="store_true", help="wgs: no arena (dk_engine_reserve): the grow-only pool allocates inside the first batches")
+    ap.add_argument("--no-other-workloads", action="store_true", help="wgs, one GPU: skip the short chr20 / ont runs attached under other_workloads")
+    ap.add_argument("--other-steps", type=int, default=4, help="timed steps of each of the other workloads")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -238,16 +319,40 @@ def main():
     for ov in args.opt:
         name, _, val = ov.partition("=")
         eng.set_option(name, int(val))
+    # ---- device memory: one arena for everything the engine allocates (dk_engine_reserve) ----------------------------------
+    # The filter is a torch tensor (the torch.distributed fallback of the all-reduce needs it to be); everything else --
+    # workspaces, read batches, the accumulator, result tables -- is carved from ONE arena reserved now, so that the one slow
+    # hipMalloc of the run (seconds for ~200 GB) is paid here, where a real host would be opening its input files, and not
+    # inside the first parent batch.  --no-reserve restores round 2's behaviour (grow-only pool, first batch pays).
+    filter_bytes = (1 << args.log2_bits) // 8
+    filt = torch.zeros(filter_bytes // 8, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    reserve_s, reserved = 0.0, 0
+    native_possible = world == 1 or (args.backend == "nccl" and not args.single_device)
+    if wgs and not args.no_reserve and native_possible:
+        free, _ = torch.cuda.mem_get_info(dev)
+        reserved = max(0, free - (5 << 30))              # torch keeps a few GB for digests / scalars
+        t0 = time.perf_counter()
+        eng.reserve(reserved)
+        reserve_s = time.perf_counter() - t0
+        progress("arena of %.1f GB reserved in %.2f s" % (reserved / 1e9, reserve_s))
+
+    def free_bytes():
+        if reserved:
+            return eng.info("pool_bytes_reserved") - eng.info("pool_bytes_in_use")
+        return torch.cuda.mem_get_info(dev)[0]
+
     def fit_batch(want, bytes_per_read, share, reserve=0):
         """reads per batch that the free device memory allows (the partition workspace and the resident reads scale with the
         batch; a larger batch amortises the sweep of the set better): `want` unless `share` of the free bytes (less
         `reserve`, set aside for later allocations) is less"""
-        free, _ = torch.cuda.mem_get_info(dev)
-        fit = int(share * max(free - reserve, 0) / bytes_per_read) // 1_000_000 * 1_000_000
+        fit = int(share * max(free_bytes() - reserve, 0) / bytes_per_read) // 1_000_000 * 1_000_000
         return max(4_000_000, min(want, fit)) if wgs else want
 
-    # parent insert at whole-genome scale: three partition levels, ~2.5 KB of workspace per read of the batch
-    pbatch = min(fit_batch(wl["parent_batch"], 2500, 0.8), reads_rank)
+    # parent insert, slab-wise: the level-1 pieces (9.2 bytes per window) + the overflow list + the reads themselves
+    win_per_read = max(L - k + 1, 1)
+    ws_per_read = 9.8 * win_per_read * (rec_bytes / 8.0) + 57
+    pbatch = min(fit_batch(wl["parent_batch"], ws_per_read, 0.9), reads_rank)
     batch = min(wl["batch"], reads_rank)
     n_batches = (reads_rank + batch - 1) // batch
     n_pbatches = (reads_rank + pbatch - 1) // pbatch
@@ -256,9 +361,6 @@ def main():
         # a batch covers the genome b*L/genome_len times: capacity planning of the bucket regions (exact for any value)
         eng.set_option("multiplicity_hint", max(2, int(2 * b * L / genome_len) + 1) if b < reads_rank else 0)
     set_hint(pbatch)
-    filter_bytes = (1 << args.log2_bits) // 8
-    filt = torch.zeros(filter_bytes // 8, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
     kset = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
     if args.set_kind == "exact":
         kset.clear()                         # an empty exact set is not all-zero memory
@@ -296,11 +398,11 @@ def main():
     progress("workspace of the parent build returned: %.1f GB" % (freed / 1e9))
     set_hint(batch)
     allreduce_ms, allreduce_bytes, allreduce_path = 0.0, 0, None
+    native = False
     if world > 1:
         # native path: the library's own RCCL communicator (dk_comm_init + dk_set_allreduce_or), as a host without torch
         # would run it; the gloo rehearsal (several ranks on one GPU) and any failure to set it up use the
         # torch.distributed composition of the same three steps
-        native = False
         if not on_host and not args.single_device:
             try:
                 comm_init_from_torch(eng)
@@ -336,17 +438,23 @@ def main():
     stage_sum, total_dev_ms, step_stats = {}, 0.0, None
     finish_stats, windows_timed, n_flushes, step_ms = None, 0, 0, []
     if wgs:
-        # hash-window passes: what one rank accumulates per pass must fit beside the filter (and, for N > 1, beside the
-        # pieces it receives from the other ranks): 2 passes up to four ranks, 1 from eight ranks on
-        R = args.windows or (wl["windows"] if world <= 4 else 1)
-        # expected absent occurrences per pass: windows with >= 1 error base, plus filter false positives on the safe side
+        # hash-window passes: one -- the occurrences of the whole hash space fit beside the filter as 6-byte records (and the
+        # multi-GPU exchange is in place, so N > 1 needs no second copy); --windows 2 = round 2's two passes
+        R = args.windows or wl["windows"]
+        # expected absent occurrences per pass: windows with >= 1 error base (7 % above what this generator yields; units
+        # have 5 sigma of room on top and spill to an overflow list of capacity / 64 records)
         p_err = 1.0 - (1.0 - wl["err"]) ** k
-        cap = int(1.12 * p_err * reads_rank * (L - k + 1) / R)
+        cap = int(1.0 * p_err * reads_rank * (L - k + 1) / R)
         acc = dk.ChildAccumulator(eng, kset, capacity_records=cap, window_index=0, window_count=R)
-        # child batch: ~1.25 KB of partition workspace per read (one hash window) + 57 bytes per resident read and step
-        # (N > 1: the pieces received from the other ranks before counting take as much room as the accumulator itself)
-        batch = min(fit_batch(wl["batch"], 1250 / R * 2 + 57 * (args.warmup + args.steps), 0.85,
-                              reserve=acc.device_bytes() * 1.05 if world > 1 else 0), reads_rank)
+        # the counting pass's result table comes from the same memory (sized from the capacity: a sixteenth of cap / min_count
+        # entries of 12 bytes, + slack); the torch.distributed fallback of the exchange receives a second copy of the store
+        table_bytes = int(cap / max(wl["min_count"], 1) / (16 if wl["min_count"] > 1 else 1) * 1.13 * 12) + (64 << 20)
+        later = table_bytes + (acc.device_bytes() * 1.05 if world > 1 and not native_possible else 0)
+        # child batch: level-1 pieces + overflow list per read of the batch (windowed passes: 1 / R of the records), plus the
+        # reads of the resident batches (57 bytes each).  At least `n_keep` batches stay resident for the timed steps; more
+        # if they fit (up to one per step: steps beyond that revisit the resident batches after a counting pass + reset)
+        n_keep = max(1, min(8, args.warmup + args.steps))
+        batch = min(fit_batch(wl["batch"], (ws_per_read - 57) / R + 57 * n_keep, 0.97, reserve=later + (1 << 30)), reads_rank)
         if world > 1:
             # the counting passes inside the loops below are collective: every rank must walk the same number of batches
             bt = torch.tensor([batch], dtype=torch.int64, device=sdev)
@@ -354,7 +462,13 @@ def main():
             batch = int(bt.item())
         n_batches = (reads_rank + batch - 1) // batch
         set_hint(batch)
-        n_res = min(n_batches, args.warmup + args.steps)
+        room = free_bytes() - later - (1 << 30) - batch * (ws_per_read - 57) / R
+        n_res = int(max(n_keep, min(n_batches, args.warmup + args.steps, room // (batch * 57))))
+        n_res = min(n_res, n_batches)
+        if world > 1:
+            nr = torch.tensor([n_res], dtype=torch.int64, device=sdev)
+            dist.all_reduce(nr, op=dist.ReduceOp.MIN)
+            n_res = int(nr.item())
         resident = []
         for b in range(n_res):
             lo, n = batch_range(b)
@@ -362,10 +476,20 @@ def main():
         progress("child: %d resident batches, accumulator of %.1f GB" % (n_res, acc.device_bytes() / 1e9))
         finish_stages, n_flushes = {}, 0
 
-        def flush():
+        exchange_bytes = [0]
+
+        def count_accumulated():
             # counting of what was accumulated is part of the job; N > 1: the ranks first swap unit ranges, so that counts
-            # and min_count are exact across the read shards (each rank ends with its share of the hash space)
-            res = accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
+            # and min_count are exact across the read shards (each rank ends with its share of the hash space) -- natively
+            # (dk_accum_exchange_finish: in place on the library's communicator) or, in the gloo rehearsal, over torch.distributed
+            if world > 1 and native:
+                res = acc.exchange_finish(min_count=wl["min_count"])
+                exchange_bytes[0] += res.bytes_sent
+                return res
+            return accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
+
+        def flush():
+            res = count_accumulated()
             st, t = res.stats, eng.timings()
             res.close()
             return st, t
@@ -378,6 +502,8 @@ def main():
                 flush()
                 acc.reset(0)
         flush()                              # warm-up of the counting stage too (its table comes from the workspace pool)
+        acc.reset(0)                         # the timed steps start on an empty accumulator, at the batch after the warm-up's last
+        since = 0                            # batches added since the last reset
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -392,7 +518,9 @@ def main():
             step_ms.append([round(ms, 2) for _, ms in t["stages"]])
             for name, ms in t["stages"]:
                 stage_sum[name] = stage_sum.get(name, 0.0) + ms
-            if (j + 1) % n_res == 0 or i == args.steps - 1:
+            since += 1
+            if since == n_res or i == args.steps - 1:
+                since = 0
                 fst, t = flush()
                 n_flushes += 1
                 finish_stats = fst if finish_stats is None else {key: finish_stats[key] + fst[key] for key in fst}
@@ -467,7 +595,7 @@ def main():
                     child_windows += st["n_windows"]
                 cb.close()
             tc = time.perf_counter()
-            res = accum_exchange_finish(acc, min_count=wl["min_count"], stage_through_cpu=on_host)
+            res = count_accumulated()
             tf = eng.timings()
             finish_dev_ms += tf["total_ms"]
             finish_wall_s += time.perf_counter() - tc
@@ -496,13 +624,16 @@ def main():
                "device_seconds_adds": add_dev_ms * 1e-3, "device_seconds_counting": finish_dev_ms * 1e-3,
                "counting_stages_ms": finish_stage_ms, "wall_seconds_counting": finish_wall_s,
                "absent_occurrences": n_absent_all, "child_only_kmers": n_child_only,
-               "trio_seconds": parent_seconds + allreduce_ms * 1e-3 + child_seconds,
-               "trio_gkmers_s": (parent_windows + child_windows) / (parent_seconds + allreduce_ms * 1e-3 + child_seconds) / 1e9,
+               "trio_seconds": reserve_s + parent_seconds + allreduce_ms * 1e-3 + child_seconds,
+               "trio_gkmers_s": (parent_windows + child_windows) / (reserve_s + parent_seconds + allreduce_ms * 1e-3 + child_seconds) / 1e9,
+               "arena_reserve_seconds_included": reserve_s,
                "parent_reads": 2 * reads_total, "parent_windows": parent_windows, "parent_seconds": parent_seconds,
                "note": "read generation (synthetic, on the GPU) is inside child_seconds / parent_seconds and subtracted for child_gkmers_s; "
                        + ("the ranks swap accumulator unit ranges before counting (dist.accum_exchange_finish): counts are exact across "
                           "the read shards, every rank keeps its share of the hash space" if world > 1 else "one GPU")}
     if wgs:
+        acc_rec_bytes = acc.geometry()[2]
+        timed_slabs = eng.info("plan_slabs")
         acc.close()
     elif world > 1:
         # chr20 / ont over several GPUs, end to end: one more child pass per rank + the cross-rank sum of the per-rank
@@ -554,13 +685,21 @@ def main():
         out = {
             "metric": "Gk-mers/sec (child reads vs parent %s), k=%d" % ("Bloom" if args.set_kind == "bloom" else "exact set", k),
             "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            # wgs deals ONE trio to the ranks (the total work is fixed); chr20 / ont bring N times the genome
+            "scaling": "strong" if wgs else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "k": k, "reads_per_sample": reads_total, "reads_per_gpu": reads_rank,
                        "reads_per_step": batch, "read_len": L, "filter_log2_bits": args.log2_bits, "n_hashes": args.n_hashes,
                        "mode": args.mode, "set_kind": args.set_kind, "hash_windows": R, "engine_options": args.opt,
                        "windows_counted_per_step": "n_windows / hash_windows",
                        "counting_passes_inside_timed_region": n_flushes if wgs else None,
+                       "resident_child_batches": n_res if wgs else 1,
+                       "level2_slabs": timed_slabs if wgs else eng.info("plan_slabs"), "level1_bits": eng.info("plan_b1"), "level2_bits": eng.info("plan_b2"),
+                       "sub_segment_split_bits": eng.info("plan_sbits"),
+                       "accumulator_record_bytes": acc_rec_bytes if wgs else None,
+                       "arena_bytes": reserved, "arena_reserve_seconds": reserve_s,
+                       "device_bytes_peak_of_the_engine": eng.info("pool_bytes_peak"),
                        "parallelism": "reads sharded x%d, %s-all-reduce of parent set" % (world, "OR" if args.set_kind == "bloom" else "union")},
             "roofline": rl,
             "stages_ms": stages,
@@ -570,6 +709,8 @@ def main():
                              "insert_ms_per_batch": insert_ms, "insert_stages_ms": insert_stages, "batches": 2 * n_pbatches,
                              "reads_per_batch": pbatch,
                              "seconds_all_batches_incl_read_generation": parent_seconds,
+                             "arena_reserve_seconds": reserve_s,
+                             "seconds_all_batches_plus_arena_reserve": parent_seconds + reserve_s,
                              "read_generation_seconds": parent_gen_s, "device_ms_of_each_batch": parent_batch_ms, "device_seconds_all_batches": parent_dev_ms * 1e-3,
                              "gkmers_s_all_batches_device_time": parent_windows / (parent_dev_ms * 1e-3) / 1e9 if parent_dev_ms else None,
                              "or_allreduce_ms": allreduce_ms, "or_allreduce_bytes_per_rank": allreduce_bytes,
@@ -586,18 +727,31 @@ def main():
             out["finish_stats"] = finish_stats
         if e2e:
             out["end_to_end"] = e2e
+        if world > 1 and wgs:
+            out["config"]["accumulator_exchange"] = ("dk_accum_exchange_finish (RCCL, in place)" if native else "torch.distributed (rehearsal / fallback)")
+            out["config"]["accumulator_exchange_bytes_sent_rank0"] = exchange_bytes[0]
         if args.set_kind == "exact":
             out["parent_build"]["exact_set_load"] = popc / (filter_bytes / (16 if k > 32 else 8))
         if world == 1 and not args.no_cpu_baseline and args.set_kind == "bloom":
             default_sample = {"wgs": 3_000_000, "chr20": 6_000_000, "ont": 12_000}[args.workload]
             progress("CPU baseline (oracle on a bounded sample, filter copied to the host)")
-            out["cpu_baseline"] = cpu_baseline(dk, eng, kset, gcfg, args, wl, min(args.cpu_sample_reads or default_sample, reads_rank))
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(dk, eng, kset, gcfg, args, wl, min(args.cpu_sample_reads or default_sample, reads_rank),
+                                               accum_windows=R if wgs else 0, slabs=timed_slabs if wgs else 0)
 
     if not wgs:
         child.close()
     kset.close()
     eng.close()
+    if rank == 0:
+        if wgs and world == 1 and not args.no_other_workloads:
+            # the other two single-GPU configurations, a few steps each, in the same process (the driver times one command)
+            del filt, kset
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {}
+            for name in ("chr20", "ont"):
+                progress("other workload: %s" % name)
+                out["other_workloads"][name] = run_probe_workload(dk, torch, name, args, args.other_steps, 2)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
