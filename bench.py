@@ -454,7 +454,8 @@ def main():
         # reads of the resident batches (57 bytes each).  At least `n_keep` batches stay resident for the timed steps; more
         # if they fit (up to one per step: steps beyond that revisit the resident batches after a counting pass + reset)
         n_keep = max(1, min(8, args.warmup + args.steps))
-        batch = min(fit_batch(wl["batch"], (ws_per_read - 57) / R + 57 * n_keep, 0.97, reserve=later + (1 << 30)), reads_rank)
+        slab_room = 9 << 30                  # one slab of level-2 regions (the engine keeps it below 12 GiB)
+        batch = min(fit_batch(wl["batch"], (ws_per_read - 57) / R + 57 * n_keep, 0.97, reserve=later + slab_room), reads_rank)
         if world > 1:
             # the counting passes inside the loops below are collective: every rank must walk the same number of batches
             bt = torch.tensor([batch], dtype=torch.int64, device=sdev)
@@ -462,7 +463,7 @@ def main():
             batch = int(bt.item())
         n_batches = (reads_rank + batch - 1) // batch
         set_hint(batch)
-        room = free_bytes() - later - (1 << 30) - batch * (ws_per_read - 57) / R
+        room = free_bytes() - later - slab_room - batch * (ws_per_read - 57) / R
         n_res = int(max(n_keep, min(n_batches, args.warmup + args.steps, room // (batch * 57))))
         n_res = min(n_res, n_batches)
         if world > 1:

@@ -324,15 +324,9 @@ static dk_status merge_results(dk_engine *e, const dk_result *const *results, ui
     };
     int pbits = e->opt.merge_pass_bits;
     while (pbits < 16 && ((2 * total) >> pbits) > (1ULL << 31)) pbits++;
-    // pass tables are sized for the mean share of a pass plus slack (hash ranges are uniform)
-    const uint64_t per_pass = (total >> pbits) + (pbits ? (total >> (pbits + 3)) + 65536 : 0);
-    const int log2_cap = std::max(10, ceil_log2(2 * per_pass));
-    const uint64_t cap = 1ULL << log2_cap;
     dk_status st = pool_alloc(e, total * 8, (void **)&lo);
     if (st == DK_OK && WIDE) st = pool_alloc(e, total * 8, (void **)&hi);
     if (st == DK_OK) st = pool_alloc(e, total * 4, (void **)&cnt);
-    if (st == DK_OK) st = pool_alloc(e, cap * sizeof(IdxT), (void **)&slots);
-    if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&counts);
     if (st == DK_OK) st = pool_alloc(e, total * 8, (void **)&res->d_lo);
     if (st == DK_OK && WIDE) st = pool_alloc(e, total * 8, (void **)&res->d_hi);
     if (st == DK_OK) st = pool_alloc(e, total * 4, (void **)&res->d_cnt);
@@ -351,23 +345,43 @@ static dk_status merge_results(dk_engine *e, const dk_result *const *results, ui
             done += c;
         }
     }
-    for (uint32_t q = 0; q < (1u << pbits) && h == hipSuccess; q++) {
-        h = hipMemsetAsync(slots, 0xFF, cap * sizeof(IdxT), e->stream);
-        if (h == hipSuccess) h = hipMemsetAsync(counts, 0, cap * 4, e->stream);
-        if (h == hipSuccess) {
-            merge_insert_kernel<WIDE, IdxT><<<grid_for(e, total, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                lo, hi, cnt, total, slots, counts, log2_cap, e->cfg.seed, pbits, q);
-            // entries are appended behind those of the earlier passes (Counters::n_emitted runs on)
-            count_emit_kernel<WIDE, IdxT><<<grid_for(e, cap, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
-                lo, hi, slots, counts, cap, min_count, e->d_ctr, res->d_lo, res->d_hi, res->d_cnt);
-            h = hipGetLastError();
+    if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "merge copies failed: %s", hipGetErrorString(h)); }
+    // pass tables are sized for the mean share of a pass plus slack (the remixed hash ranges are uniform); should a pass
+    // still not fit -- the kernel reports it instead of spinning -- the whole merge is redone with tables twice the size
+    const uint64_t per_pass = (total >> pbits) + (pbits ? (total >> (pbits + 3)) + 65536 : 0);
+    int log2_cap = std::max(e->opt.merge_undersize ? 4 : 10, ceil_log2(2 * per_pass) - e->opt.merge_undersize);   // (test hook: start too small)
+    for (int attempt = 0;; attempt++) {
+        const uint64_t cap = 1ULL << log2_cap;
+        st = pool_alloc(e, cap * sizeof(IdxT), (void **)&slots);
+        if (st == DK_OK) st = pool_alloc(e, cap * 4, (void **)&counts);
+        if (st != DK_OK) { cleanup(); return st; }
+        for (uint32_t q = 0; q < (1u << pbits) && h == hipSuccess; q++) {
+            h = hipMemsetAsync(slots, 0xFF, cap * sizeof(IdxT), e->stream);
+            if (h == hipSuccess) h = hipMemsetAsync(counts, 0, cap * 4, e->stream);
+            if (h == hipSuccess) {
+                merge_insert_kernel<WIDE, IdxT><<<grid_for(e, total, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    lo, hi, cnt, total, slots, counts, log2_cap, e->cfg.seed, pbits, q, e->d_ctr);
+                // entries are appended behind those of the earlier passes (Counters::n_emitted runs on)
+                count_emit_kernel<WIDE, IdxT><<<grid_for(e, cap, DIRECT_BLOCK), DIRECT_BLOCK, 0, e->stream>>>(
+                    lo, hi, slots, counts, cap, min_count, e->d_ctr, res->d_lo, res->d_hi, res->d_cnt);
+                h = hipGetLastError();
+            }
         }
+        if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "merge kernels failed: %s", hipGetErrorString(h)); }
+        stage_mark(e, attempt ? "merge_redo" : "merge");
+        st = read_counters(e);
+        if (st != DK_OK) { cleanup(); return st; }
+        if (!e->h_ctr->n_overflow) break;
+        if (attempt == 3) { cleanup(); return fail(e, DK_ERR_OVERFLOW, "merge: the pass tables overflowed four times over"); }
+        pool_free(e, slots);
+        pool_free(e, counts);
+        slots = nullptr;
+        counts = nullptr;
+        log2_cap++;
+        h = hipMemsetAsync(e->d_ctr, 0, sizeof(Counters), e->stream);
+        if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(h)); }
     }
-    if (h != hipSuccess) { cleanup(); return fail(e, DK_ERR_HIP, "merge kernels failed: %s", hipGetErrorString(h)); }
-    stage_mark(e, "merge");
-    st = read_counters(e);
     cleanup();
-    if (st != DK_OK) return st;
     res->n = e->h_ctr->n_emitted;
     res->n_regions = 1;
     res->region_cap = total;
@@ -722,6 +736,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"accum_plain", &dk_options::accum_plain, 0, 1},
         {"accum_min_u", &dk_options::accum_min_u, 0, 10},
         {"mode", &dk_options::mode, 0, 2},
+        {"merge_undersize", &dk_options::merge_undersize, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},

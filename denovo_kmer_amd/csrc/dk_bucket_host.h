@@ -158,7 +158,10 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
         if (e->opt.slabs > 0) {
             while (S * 2 <= (uint32_t)e->opt.slabs && S * 2 <= max_slabs) S *= 2;
         } else {
-            const uint64_t budget = (uint64_t)(e->opt.slab_mb > 0 ? e->opt.slab_mb : 1024) << 20;
+            // (fewer, larger slabs are faster -- every launch ends with a tail of half-empty CUs: 8 slabs 83.3 Gk-mers/s,
+            // 64 slabs 79.5, 128 slabs 77.5 on the whole-genome child step -- and nothing of a slab survives in the
+            // Infinity Cache between its two kernels anyway; 12 GiB keeps the whole-genome child at 8 slabs)
+            const uint64_t budget = (uint64_t)(e->opt.slab_mb > 0 ? e->opt.slab_mb : 12288) << 20;
             const uint64_t rec_bytes = wide ? 16 : 8;
             while (S < max_slabs && p->n_seg * (uint64_t)p->cap2 * rec_bytes / S > budget) S *= 2;
         }

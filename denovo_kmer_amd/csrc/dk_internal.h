@@ -45,7 +45,7 @@ struct dk_options {
     int cnt_split_to = 0;         // absent-list split: records per unit aimed at (default 6000, k > 32: 3000)
     int repart_bits = 0;          // repart: most hash bits one pass may take (default 10; 9 = round 1's limit, for A/B runs)
     int slabs = 0;                // slab-wise level 2 of insert / accumulate: number of slabs (0 = automatic; a power of two)
-    int slab_mb = 0;              // automatic slabs: room for one slab's regions in MiB (default 1024)
+    int slab_mb = 0;              // automatic slabs: room for one slab's regions in MiB (default 12288)
     int ovf_cap = 0;              // capacity of the partition's overflow list in records (test hook; 0 = an eighth of the batch)
     int accum_min_u = 0;          // dk_accum_create: at least 2^n counting units per segment (test hook: packed units on small sets)
     int mode = 0;                 // kernel family override: 0 = dk_config.mode, 1 = direct, 2 = bucketed
@@ -56,6 +56,7 @@ struct dk_options {
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes
     int accum_unit_cap = 0;       // dk_accum_create: records per counting unit, when at least what the capacity needs (test hook)
     int sink_plain = 0;           // dk_probe: never sink the absent records into finer counting units (test hook)
+    int merge_undersize = 0;      // dk_result_merge: start with pass tables 2^n times too small (test hook: the redo path)
     int merge_idx64 = 0;          // dk_result_merge: 64-bit candidate indices whatever the size
 };
 

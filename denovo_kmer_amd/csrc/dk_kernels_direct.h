@@ -363,34 +363,42 @@ count_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__rest
 }
 
 // merge of (k-mer, count) tables: same table as count_insert, the entry's count is added.  The table is built
-// for one hash range at a time (pass q of 2^pbits: the candidates whose hash starts with the bits of q), which
-// bounds its size, and slots hold 64-bit candidate indices once there are 2^32 - 1 candidates or more.
+// for one hash range at a time (pass q of 2^pbits), which bounds its size, and slots hold 64-bit candidate indices
+// once there are 2^32 - 1 candidates or more.  Pass and slot come from a REMIX of the k-mer's hash, not from its top
+// bits: the tables of one accumulator window all share their top hash bits, and taken as they are they would fall into
+// one pass (a table sized for a 1 / 2^pbits share then overflows) and into one corner of the table.  The probe is
+// bounded by the table size: a table that is full anyway reports it (n_overflow) instead of spinning, and the host
+// redoes the merge with larger pass tables.
 template <class IdxT> struct SlotOf { static constexpr IdxT EMPTY = (IdxT)~(IdxT)0; };
+
+__host__ __device__ __forceinline__ uint64_t merge_mix(uint64_t h) { return (h ^ (h >> 32)) * 0x9E3779B97F4A7C15ULL; }
 
 template <bool WIDE, class IdxT>
 __global__ void __launch_bounds__(DIRECT_BLOCK)
 merge_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__restrict__ cand_hi,
                     const uint32_t *__restrict__ cand_cnt, uint64_t n_cand, IdxT *slots, uint32_t *counts,
-                    int log2_cap, uint64_t seed, int pbits, uint32_t q)
+                    int log2_cap, uint64_t seed, int pbits, uint32_t q, Counters *ctr)
 {
     constexpr IdxT EMPTY = SlotOf<IdxT>::EMPTY;
     const uint64_t cap_mask = (1ULL << log2_cap) - 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t n_lost = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cand; i += stride) {
         Kmer km{WIDE ? cand_hi[i] : 0, cand_lo[i]};
-        const uint64_t h = hash_kmer<WIDE>(km, seed);
+        const uint64_t h = merge_mix(hash_kmer<WIDE>(km, seed));
         if (pbits && (uint32_t)(h >> (64 - pbits)) != q) continue;
         uint64_t s = ((h << pbits) >> (64 - log2_cap)) & cap_mask;
-        for (;;) {
+        bool placed = false;
+        for (uint64_t tries = 0; tries <= cap_mask; tries++) {
             IdxT cur = slots[s];
             if (cur == EMPTY) {
                 if constexpr (sizeof(IdxT) == 8) cur = (IdxT)atomicCAS((unsigned long long *)&slots[s], (unsigned long long)EMPTY, (unsigned long long)i);
                 else cur = (IdxT)atomicCAS((unsigned int *)&slots[s], (unsigned int)EMPTY, (unsigned int)i);
             }
-            if (cur == EMPTY) break;                            // claimed
-            if (cand_lo[cur] == km.lo && (!WIDE || cand_hi[cur] == km.hi)) break;
+            if (cur == EMPTY || (cand_lo[cur] == km.lo && (!WIDE || cand_hi[cur] == km.hi))) { placed = true; break; }   // claimed, or its key
             s = (s + 1) & cap_mask;
         }
+        if (!placed) { n_lost++; continue; }                    // table full: the host redoes the merge with more room
         // saturating add: a count never wraps
         const uint32_t add = cand_cnt[i];
         uint32_t old = counts[s];
@@ -401,6 +409,7 @@ merge_insert_kernel(const uint64_t *__restrict__ cand_lo, const uint64_t *__rest
             old = seen;
         }
     }
+    if (n_lost) atomicAdd(&ctr->n_overflow, (unsigned long long)n_lost);
 }
 
 template <bool WIDE, class IdxT = uint32_t>

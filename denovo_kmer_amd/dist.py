@@ -118,14 +118,24 @@ def accum_exchange_finish(acc, min_count=1, group=None, stage_through_cpu=False)
     dev = torch.device("cuda", eng.device_id)
     n_units, cap, rb = acc.geometry()
     assert n_units % world == 0, "the units of a window split evenly over a power-of-two number of ranks"
+    # a rank whose accumulator is unusable (it lost records in an earlier call) must not leave the others inside the
+    # collectives below: its state travels with the geometry check, and every rank raises when any rank failed
+    view, failure = None, None
+    try:
+        view = acc.device_view()
+    except Exception as exc:                               # noqa: BLE001 -- reported on every rank below
+        failure = exc
     # the slices are interpreted with THIS rank's geometry: every rank must have created its accumulator alike
-    geo = torch.tensor([n_units, -n_units, cap, -cap, rb, -rb], dtype=torch.int64, device="cpu" if stage_through_cpu else dev)
+    geo = torch.tensor([n_units, -n_units, cap, -cap, rb, -rb, 1 if failure else 0], dtype=torch.int64,
+                       device="cpu" if stage_through_cpu else dev)
     dist.all_reduce(geo, op=dist.ReduceOp.MAX, group=group)
+    if int(geo[6]):
+        raise RuntimeError("accumulator exchange abandoned on every rank: %s" % (failure or "another rank's accumulator failed"))
     if any(int(geo[i]) != -int(geo[i + 1]) for i in (0, 2, 4)):
         raise ValueError("accumulators differ between ranks (units, unit capacity or record size): create them with the "
                          "same capacity_records and window_count on every rank")
     upr = n_units // world
-    sp, fp, op, n_ovf = acc.device_view()
+    sp, fp, op, n_ovf = view
     store = _device_bytes(sp, n_units * cap * rb, dev).view(world, upr * cap * rb)
     fill = _device_bytes(fp, n_units * 4, dev).view(torch.int32).view(world, upr)
 

@@ -32,6 +32,12 @@ def test_cli_compiles_and_prints_usage(tmp_path):
     assert r.returncode == 2 and "usage" in r.stderr
     r = subprocess.run([exe, "--child", "x", "--out", "y"], capture_output=True, text=True)
     assert r.returncode == 2 and "--parent" in r.stderr
+    # geometry the accumulator cannot take is a usage error, not an arithmetic accident further down
+    ok = ["--parent", "p", "--child", "x", "--out", "y"]
+    for bad, word in ((["--filter-log2", "19"], "20..40"), (["--filter-log2", "41"], "20..40"), (["--k", "65"], "1..64"),
+                      (["--filter-log2", "22", "--windows", "8"], "at most 4 hash window"), (["--windows", "3"], "power of two")):
+        r = subprocess.run([exe] + ok + bad, capture_output=True, text=True)
+        assert r.returncode == 2 and word in r.stderr, (bad, r.stderr)
 
 
 @pytest.mark.gpu

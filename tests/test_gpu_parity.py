@@ -573,6 +573,49 @@ def test_result_merge_equals_whole_sample(rng, mode, k, merge_options):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+@pytest.mark.parametrize("k", [31, 45])
+@pytest.mark.parametrize("pass_bits,undersize", [(0, 0), (2, 0), (5, 0), (8, 0), (3, 6), (0, 2)])
+def test_merging_the_tables_of_one_hash_window(k, pass_bits, undersize):
+    """the tables an accumulator returns for ONE hash window share their top hash bits: merge passes and table slots come
+    from a remix of the hash, so every pass takes its share (round 2's merge put such inputs into one pass, whose table
+    then overflowed and the insert kernel span forever).  merge_undersize starts with tables too small: the bounded
+    probe reports it and the merge is redone with larger ones ("merge_redo")."""
+    d = dk()
+    rng = np.random.default_rng(31)
+    reads = random_reads(rng, 3000, 150, 151)
+    reads = reads + reads[:700]
+    seq, off = orc.concat_reads(reads)
+    km, cn, ost = orc.count_reads(k, True, seq, off)
+    hashes = np.array([orc.hash_kmer(int(h), int(l), k, 3) for h, l in zip(km["hi"], km["lo"])], dtype=np.uint64)
+    with d.Engine(k=k, filter_log2_bits=24, seed=3, mode="bucketed") as eng:
+        eng.set_option("merge_pass_bits", pass_bits)
+        eng.set_option("merge_undersize", undersize)
+        acc = d.ChildAccumulator(eng, None, capacity_records=600_000, window_count=8)
+        total = 0
+        for w in (0, 5):
+            # the window's k-mers arrive as three tables (three finishes of three partial accumulations)
+            parts = []
+            for a, b in ((0, 1500), (1500, 1501), (1501, len(reads))):
+                acc.reset(w)
+                acc.add(d.ReadBatch.from_sequences(eng, reads[a:b]))
+                parts.append(acc.finish(min_count=1))
+            for mc in (1, 2):
+                merged = d.KmerCounter(eng).merge(parts, min_count=mc)
+                names = [n for n, _ in eng.timings()["stages"]]
+                assert ("merge_redo" in names) == bool(undersize), names
+                hi, lo, cnt = merged.to_host(sort=True)
+                # the oracle's table, restricted to the window: top 3 bits of the k-mer's hash
+                sel = ((hashes >> np.uint64(61)) == np.uint64(w)) & (cn >= mc)
+                assert np.array_equal(lo, km["lo"][sel]) and np.array_equal(hi, km["hi"][sel]) and np.array_equal(cnt, cn[sel])
+                if mc == 1:
+                    total += len(lo)
+                merged.close()
+            for p in parts:
+                p.close()
+        assert total > 0
+        acc.close()
+
+
 def test_filter_save_and_load(tmp_path, rng):
     d = dk()
     reads = random_reads(rng, 200, 80, 140)

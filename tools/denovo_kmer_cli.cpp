@@ -78,7 +78,7 @@ private:
 
 struct Args {
     uint32_t k = 31, filter_log2 = 30, hashes = 4, min_count = 1, mode = DK_MODE_AUTO, windows = 1;
-    uint64_t seed = 0x5EED, batch_reads = 2000000, accum_capacity = 64000000;
+    uint64_t seed = 0x5EED, batch_reads = 2000000, accum_capacity = 0;        // capacity 0 = from the child file's size
     bool canonical = true, exact = false;
     std::vector<std::string> parents;
     std::string child, out, save_filter, load_filter;
@@ -89,8 +89,9 @@ struct Args {
     std::fprintf(stderr, "%s\nusage: denovo_kmer_cli --k K --filter-log2 N --parent FILE [--parent FILE ...] --child FILE --out FILE\n"
                          "       [--hashes 4] [--seed N] [--min-count 1] [--batch-reads 2000000] [--mode auto|direct|bucketed]\n"
                          "       [--save-filter FILE] [--load-filter FILE] [--forward-only] [--exact]\n"
-                         "       [--windows 1] [--accum-capacity 64000000]   (child-only occurrences expected per hash window;\n"
-                         "        the child file is read once per window)\n", msg);
+                         "       [--windows 1] [--accum-capacity N]   (child-only occurrences expected per hash window; default: 30 %% of\n"
+                         "        the child file's bases / windows, at least 64 M; the child file is read once per window)\n"
+                         "       k 1..64, filter-log2 20..40, windows a power of two <= 2^(filter-log2 - 20)\n", msg);
     std::exit(2);
 }
 
@@ -127,6 +128,12 @@ Args parse(int argc, char **argv)
     if (a.parents.empty() && a.load_filter.empty()) usage("give --parent files or --load-filter");
     if (a.batch_reads == 0) usage("--batch-reads must be positive");
     if (a.windows == 0 || (a.windows & (a.windows - 1))) usage("--windows must be a power of two");
+    if (a.k < 1 || a.k > 64) usage("--k must be 1..64");
+    if (a.filter_log2 < 20 || a.filter_log2 > 40) usage("--filter-log2 must be 20..40");
+    // every hash window covers at least two 64-KiB segments of the set (dk_accum_create)
+    if ((uint64_t)a.windows > (1ULL << (a.filter_log2 - 20)))
+        usage(("--windows " + std::to_string(a.windows) + ": a set of 2^" + std::to_string(a.filter_log2) + " bits takes at most " +
+               std::to_string(1ULL << (a.filter_log2 - 20)) + " hash window(s)").c_str());
     return a;
 }
 
@@ -189,7 +196,19 @@ int main(int argc, char **argv)
         // the child's absent k-mer occurrences stay on the GPU across batches and are counted once per hash window
         // (what one hash window of this set geometry can count: 1024 units of 12288 (k > 32: 6144) records per 64-KiB segment)
         const uint64_t geometry_max = (1ULL << (a.filter_log2 - 19)) / a.windows * 1024 * (a.k > 32 ? 6144 : 12288);
-        dk_host::ChildAccumulator acc(eng, &parents, std::min<uint64_t>(a.accum_capacity, geometry_max), a.windows);
+        uint64_t capacity = a.accum_capacity;
+        if (!capacity) {
+            // not given: 30 % of the child's windows may be absent (reads with 0.5 % errors leave ~14 % at k = 31), spread
+            // over the hash windows; the file's size bounds its bases (FASTQ spends as many bytes on qualities)
+            std::ifstream probe(a.child, std::ios::binary | std::ios::ate);
+            if (!probe) throw std::runtime_error("cannot open " + a.child);
+            const uint64_t bytes = (uint64_t)probe.tellg();
+            probe.seekg(0);
+            const uint64_t bases = probe.peek() == '@' ? bytes / 2 : bytes;
+            capacity = std::max<uint64_t>(64000000 / a.windows, bases * 3 / 10 / a.windows);
+        }
+        capacity = std::max<uint64_t>(1, std::min<uint64_t>(capacity, geometry_max));
+        dk_host::ChildAccumulator acc(eng, &parents, capacity, a.windows);
         dk_host::KmerCounts res{};
         uint64_t n_child = 0, n_batches = 0;
         for (uint32_t w = 0; w < a.windows; w++) {
@@ -217,6 +236,10 @@ int main(int argc, char **argv)
         for (size_t i : order) out << kmer_string(res.hi[i], res.lo[i], a.k) << '\t' << res.count[i] << '\n';
     } catch (const dk_host::Error &e) {
         std::fprintf(stderr, "denovo_kmer error %d: %s\n", (int)e.status, e.what());
+        if (e.status == DK_ERR_OVERFLOW)
+            std::fprintf(stderr, "the child holds more absent k-mer occurrences per hash window than the accumulator was sized for: "
+                                 "raise --accum-capacity (%s) or --windows (%u)\n",
+                         a.accum_capacity ? std::to_string(a.accum_capacity).c_str() : "automatic", a.windows);
         return 1;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
