@@ -45,6 +45,7 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
     words = (1 << log2_bits) // 64
     with d.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=nh, seed=seed, mode="bucketed") as eng:
         eng.reserve(60 << 30)                                         # workspace arena: no hipMalloc inside the calls below
+        eng.set_option("slab_mb", 512)          # 4 M-read batches take several slabs, as the 48 M-read ones of bench.py do at 12 GiB
         fb = torch.zeros(words, dtype=torch.int64, device="cuda")
         fd = torch.zeros(words, dtype=torch.int64, device="cuda")
         ks = d.KmerSet(eng, device_ptr=fb.data_ptr(), keepalive=fb)
