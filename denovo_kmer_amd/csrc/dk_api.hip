@@ -734,6 +734,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"slab_mb", &dk_options::slab_mb, 0, 1 << 20},
         {"ovf_cap", &dk_options::ovf_cap, 0, 1 << 30},
         {"accum_plain", &dk_options::accum_plain, 0, 1},
+        {"l2_packed", &dk_options::l2_packed, 0, 1},
         {"accum_min_u", &dk_options::accum_min_u, 0, 10},
         {"mode", &dk_options::mode, 0, 2},
         {"merge_undersize", &dk_options::merge_undersize, 0, 10},
@@ -1681,8 +1682,7 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
         // channels -- 2966 ms instead of 55 for the 9.6 x 10^9 records of a whole-genome pass; every other stride tried
         // (20..32 x 4 KiB + 128 B, 96 KiB exactly, odd sizes) takes the same 55 ms (tools/experiments/accum_count.py).
         // The smallest such capacity that leaves 5 sigma of room (the rare unit beyond it spills to the overflow list).
-        // Packed units (6-byte records): a multiple of 64 records (both arrays of the unit stay 128-byte aligned) whose
-        // stride in bytes is not a multiple of 16 KiB.
+        // Packed units (6-byte records): whole 64-record blocks, and a stride in bytes that is not a multiple of 16 KiB.
         const double sig = s ? 1.0 : sqrt(segment_ratio(e));
         const uint32_t need = (uint32_t)(mean + 5.0 * sig * sqrt(mean + 1.0)) + 1u;
         if (a->packed) {
@@ -1693,7 +1693,7 @@ dk_status dk_accum_create(dk_engine *e, dk_set *s, uint32_t window_index, uint32
             a->unit_cap = (need > odd ? (need - odd + per_4k - 1) / per_4k * per_4k : 0u) + odd;
         }
         if ((uint32_t)e->opt.accum_unit_cap >= need) a->unit_cap = (uint32_t)e->opt.accum_unit_cap;
-        if (a->packed) a->unit_cap = (a->unit_cap + 1) & ~1u;           // (a forced capacity: the u16 array stays 4-byte aligned)
+        if (a->packed) a->unit_cap = (a->unit_cap + 63) / 64 * 64;      // (a forced capacity too: whole 64-record blocks)
     }
     a->store = nullptr;
     a->fill = nullptr;

@@ -57,6 +57,7 @@ struct BucketPlan {
     // segments, next slab -- so the regions need 1 / slabs of the room (2^39 bits, 32 M reads: 40 GB -> 0.6-5 GB), which is
     // what lets a whole-genome child pass run in ONE hash window beside the filter and a full-size accumulator.
     uint32_t slabs, slab_bins;
+    bool packed2;          // level-2 regions hold packed 6-byte records (k <= 32, two levels, >= 16 prefix bits per region)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
@@ -145,6 +146,29 @@ __device__ __forceinline__ void store_global(Rec2 *dst, const Rec2 &r)
     v.x = r.h;
     v.y = r.hi;
     *(__attribute__((address_space(1))) dk_ull2 *)dst = v;
+}
+
+// Packed records (k <= 32): where all records of a group share at least 16 leading hash bits -- the counting units of an
+// accumulator (T + u bits: every accumulator of a set of 2^28 bits or more) and the level-2 regions of a partition
+// (window + b1 + b2 bits: sets of 2^35 bits or more) -- only the low 48 bits are kept: 6 bytes per record instead of 8.
+// A group of `cap` records (a multiple of 64) is a row of 384-byte blocks, each holding 64 records as 64 x u32 (hash bits
+// 0..31) followed by 64 x u16 (bits 32..47): everything stays naturally aligned, a wave's 64 consecutive records are one
+// block (two fully coalesced accesses), and -- what decides the speed of the kernels that APPEND to many groups at once --
+// a group has ONE write frontier of three cache lines.  (Two separate arrays per group, cap x u32 then cap x u16, gave
+// every group two frontiers tens of KB apart: repart 21.5 -> 26.3 ms on the whole-genome child step.)
+constexpr int PACKED_REC_BYTES = 6;
+constexpr int PACKED_MIN_PREFIX_BITS = 16;
+constexpr int PACKED_BLOCK_RECS = 64, PACKED_BLOCK_BYTES = PACKED_BLOCK_RECS * PACKED_REC_BYTES;
+__device__ __forceinline__ void packed_store(void *store, uint64_t unit, uint32_t cap, uint32_t pos, uint64_t h)
+{
+    char *blk = (char *)store + unit * (uint64_t)cap * PACKED_REC_BYTES + (uint64_t)(pos >> 6) * PACKED_BLOCK_BYTES;
+    ((uint32_t *)blk)[pos & 63] = (uint32_t)h;
+    ((uint16_t *)(blk + PACKED_BLOCK_RECS * 4))[pos & 63] = (uint16_t)(h >> 32);
+}
+__device__ __forceinline__ uint64_t packed_load(const void *store, uint64_t unit, uint32_t cap, uint32_t pos, uint64_t prefix)
+{
+    const char *blk = (const char *)store + unit * (uint64_t)cap * PACKED_REC_BYTES + (uint64_t)(pos >> 6) * PACKED_BLOCK_BYTES;
+    return prefix | ((uint64_t)((const uint16_t *)(blk + PACKED_BLOCK_RECS * 4))[pos & 63] << 32) | ((const uint32_t *)blk)[pos & 63];
 }
 
 template <class R>

@@ -88,6 +88,7 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
     const bool wide = e->cfg.k > 32;
     p->sbits = sbits;
     p->slabs = 1;
+    p->packed2 = false;
     p->T = (T_override > 0 ? T_override : set_segment_bits(e)) - wbits - sbits;
     if (p->T < 1 || p->T > MAX_SEG_BITS) return false;
     p->b3 = 0;
@@ -168,6 +169,16 @@ inline bool make_plan(const dk_engine *e, const dk_reads *r, BucketPlan *p, int 
         p->slabs = S;
     }
     p->slab_bins = p->p1 / p->slabs;
+    // (the flows that take slabs -- insert and accumulate -- are the ones whose set kernels read packed regions)
+    // Off unless option "l2_packed" asks for it: the regions' 16 fewer bits per record save 12 % of repart's writes and 25 % of
+    // the set kernels' record reads, but a record then takes TWO store instructions in repart's copy-out (u32 + u16), and that
+    // kernel is bound by its store issue rate: whole-genome child step repart 21.4 -> 27.2 ms against seg_probe 22.3 -> 22.6
+    // (no gain: not bound by its record reads); parent batch repart 50.7 -> 55.9, seg_insert 51.7 -> 46.0 ms.
+    p->packed2 = allow_slabs && !wide && !p->b3 && e->opt.l2_packed && wbits + p->T >= PACKED_MIN_PREFIX_BITS;
+    if (p->packed2) {
+        p->cap2 = (p->cap2 + 63) / 64 * 64;                      // whole 64-record blocks
+        if (((uint64_t)p->cap2 * PACKED_REC_BYTES) % 16384 == 0) p->cap2 += 64;
+    }
     return true;
 }
 
@@ -233,7 +244,11 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
             p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \
     } while (0)
     if constexpr (WIDE) DK_REPART_LAUNCH(512, 8, 8);
-    else if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
+    else if (p.packed2) {
+        const uint32_t tpp = (p.capw + 1024 * 8 - 1) / (1024 * 8);
+        repart_kernel<1024, 8, 8, R, true><<<repart_grid(p.G * tpp, p.slab_bins), 1024, 0, e->stream>>>(
+            B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.cap2, B.b, B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);
+    } else if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
     else DK_REPART_LAUNCH(1024, 8, 8);
 #undef DK_REPART_LAUNCH
 }
@@ -262,7 +277,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     const uint64_t a_recs = p.b3 ? std::max(seg_recs, lvl1_recs) : std::max(need_scratch ? seg_recs : 0, lvl1_recs);
     const uint64_t b_recs = p.b3 ? std::max(need_scratch ? seg_recs : 0, coarse_recs) : seg_recs;
     DK_TRY(pool_alloc(e, a_recs * sizeof(R), (void **)&B.a));
-    DK_TRY(pool_alloc(e, b_recs * sizeof(R), (void **)&B.b));
+    DK_TRY(pool_alloc(e, p.packed2 ? seg_recs * PACKED_REC_BYTES : b_recs * sizeof(R), (void **)&B.b));
     const uint64_t n1 = (uint64_t)p.p1 * p.G;
     DK_TRY(pool_alloc(e, (n1 + 2 * p.n_seg + n_coarse) * 4, (void **)&B.cnt));
     B.cnt1 = B.cnt;
@@ -334,10 +349,13 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 
 // the piece list of slab `slab`'s regions (B.b holds one slab at a time; the region counts are indexed globally)
 template <class R>
-inline PieceList<R> slab_piece_list(const BucketPlan &p, const BucketBufs<R> &B, uint32_t slab)
+inline PieceList<R> slab_piece_list(const BucketPlan &p, const BucketBufs<R> &B, uint32_t slab, int wbits = 0, uint32_t widx = 0)
 {
     const uint64_t regions_per_slab = p.n_seg / p.slabs;
-    return PieceList<R>{B.rec, B.cursor2 + slab * regions_per_slab, 1, p.cap2, nullptr, nullptr};
+    PieceList<R> pl{B.rec, B.cursor2 + slab * regions_per_slab, 1, p.cap2, nullptr, nullptr};
+    pl.pk_bits = wbits + p.T;                                    // (read by the packed kernels only)
+    pl.pk_region0 = ((uint64_t)widx << p.T) + slab * regions_per_slab;
+    return pl;
 }
 
 // copy the device counters to the host; the absent tallies of the segment kernels (Counters::shard) are folded
@@ -392,7 +410,19 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
             pl.sbits = p.sbits;
             pl.sub_shift = 64 - T_full;
             const uint64_t seg_base = (uint64_t)sl * n_seg;
-            if (s->exact)
+            bool launched = false;
+            if constexpr (!WIDE) {
+                if (p.packed2) {
+                    if (s->exact)
+                        seg_exact_insert_kernel<R, true><<<n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, T_full, e->d_ctr, seg_base);
+                    else
+                        seg_insert_kernel<R, true><<<n_seg, SEG_THREADS, 0, e->stream>>>(
+                            s->d_words, pl, (int)e->cfg.n_hashes, 64 - T_full - SEG_LOG2_BLOCKS, seg_base);
+                    launched = true;
+                }
+            }
+            if (launched) {
+            } else if (s->exact)
                 seg_exact_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, pl, T_full, e->d_ctr, seg_base);
             else
                 seg_insert_kernel<R><<<n_seg, SEG_THREADS, 0, e->stream>>>(
@@ -421,17 +451,17 @@ inline dk_status bucketed_insert_t(dk_engine *e, dk_set *s, const dk_reads *r)
 // independent workgroups overlap their load / probe phases better than fewer, longer ones.)
 // the membership kernel of one batch over the n_seg segments from seg_base on (the set's kind and hash count pick the
 // instance); s == nullptr is only valid with ACC: every record is absent
-template <class R, int ACC>
+template <class R, int ACC, bool PK = false>
 inline hipError_t launch_seg_probe(dk_engine *e, dk_set *s, const PieceList<R> &list, uint64_t n_seg, int T_full,
                                    uint64_t seg_base, const MissOut<R> &mo)
 {
     const int blk_shift = 64 - T_full - SEG_LOG2_BLOCKS;
     if (s && s->exact)
-        seg_exact_probe_kernel<R, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, T_full, seg_base, mo, e->d_ctr);
+        seg_exact_probe_kernel<R, ACC, PK><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, T_full, seg_base, mo, e->d_ctr);
     else if (s && e->cfg.n_hashes == 4)
-        seg_probe_kernel<R, 4, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, 4, blk_shift, seg_base, mo, e->d_ctr);
+        seg_probe_kernel<R, 4, ACC, PK><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(s->d_words, list, 4, blk_shift, seg_base, mo, e->d_ctr);
     else
-        seg_probe_kernel<R, 0, ACC><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
+        seg_probe_kernel<R, 0, ACC, PK><<<(unsigned)n_seg, SEG_THREADS, 0, e->stream>>>(
             s ? s->d_words : nullptr, list, s ? (int)e->cfg.n_hashes : 0, blk_shift, seg_base, mo, e->d_ctr);
     return hipGetLastError();
 }
@@ -771,7 +801,7 @@ inline dk_status bucketed_accum_add_t(dk_engine *e, dk_accum *a, const dk_reads 
             launch_repart<WIDE>(e, p, B, a->wbits, sl);
             stage_mark(e, "repart");
         }
-        PieceList<R> list = slab_piece_list(p, B, sl);
+        PieceList<R> list = slab_piece_list(p, B, sl, a->wbits, a->widx);
         list.sbits = p.sbits;
         list.sub_shift = 64 - a->T;
         // the slab's first unit inside the window: the sink addresses units from there
@@ -782,10 +812,11 @@ inline dk_status bucketed_accum_add_t(dk_engine *e, dk_accum *a, const dk_reads 
         const uint64_t seg_base = win_seg0 + (uint64_t)sl * segs_per_slab;
         bool launched = false;
         if constexpr (!WIDE) {
-            if (a->packed) {
-                h = launch_seg_probe<R, ACC_PACKED>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
-                launched = true;
-            }
+            launched = true;
+            if (a->packed && p.packed2) h = launch_seg_probe<R, ACC_PACKED, true>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
+            else if (a->packed) h = launch_seg_probe<R, ACC_PACKED, false>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
+            else if (p.packed2) h = launch_seg_probe<R, ACC_PLAIN, true>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
+            else launched = false;
         }
         if (!launched) h = launch_seg_probe<R, ACC_PLAIN>(e, a->s, list, segs_per_slab, a->T, seg_base, ms);
         if (h == hipSuccess) stage_mark(e, probe_name);

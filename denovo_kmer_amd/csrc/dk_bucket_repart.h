@@ -10,7 +10,8 @@ namespace dk {
 // hot (every resident workgroup appends to the same 2^b2 segments of one coarse bin at a time),
 // which measured faster than private level-2 pieces; the cursor atomics are issued before the
 // scatter phase and only waited for after it, so their latency is covered.
-template <int THREADS, int PER_THREAD, int MIN_WAVES, class R>
+// PK (k <= 32, regions of >= 16 prefix bits): the regions receive packed 6-byte records (dk_bucket_common.h)
+template <int THREADS, int PER_THREAD, int MIN_WAVES, class R, bool PK = false>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
@@ -104,7 +105,8 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
             const R rec = L.stage[i];
             const uint32_t bin = bin_of(rec.h);
             const uint32_t idx = i + L.delta[bin];       // 32-bit on purpose: delta is a wrapped difference
-            out[(seg0 + bin) * cap2 + idx] = rec;
+            if constexpr (PK) packed_store(out, seg0 + bin, cap2, idx, rec.h);
+            else out[(seg0 + bin) * cap2 + idx] = rec;
         }
     } else {
 #pragma unroll 2
@@ -112,7 +114,10 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
             const R rec = L.stage[i];
             const uint32_t bin = bin_of(rec.h);
             const uint32_t idx = i + L.delta[bin];
-            if (idx < cap2) out[(seg0 + bin) * cap2 + idx] = rec;
+            if (idx < cap2) {
+                if constexpr (PK) packed_store(out, seg0 + bin, cap2, idx, rec.h);
+                else out[(seg0 + bin) * cap2 + idx] = rec;
+            }
             ovf_append(ovf, idx >= cap2, rec, n_overflow);
         }
     }

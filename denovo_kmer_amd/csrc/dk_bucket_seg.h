@@ -23,6 +23,10 @@ struct PieceList {
     // equal g's low sbits.  The last partition bits are thus resolved by 2^sbits workgroups re-reading one region
     // (mostly from L2 / Infinity Cache) instead of by one more multisplit pass over HBM.
     int sbits = 0, sub_shift = 0;
+    // Packed regions (set kernels with PK): region g of the launch holds piece_cap packed records (dk_bucket_common.h) whose
+    // hashes all start with the region's global index, pk_region0 + g, in their top pk_bits bits
+    int pk_bits = 0;
+    uint64_t pk_region0 = 0;
     // Piece-major layout (the receiving side of a multi-GPU exchange: n_pieces slices, one per rank, each holding the
     // same n_segs units): piece r of segment s = recs[(r * n_segs + s) * piece_cap ...], cnt[r * n_segs + s].  0 = segment-major.
     uint64_t n_segs = 0;
@@ -138,7 +142,7 @@ __device__ __forceinline__ void stage_segment(uint32_t *seg, const SegRegs &r)
 
 // seg_base: the launch covers the segments seg_base .. seg_base + gridDim.x of the set (one slab of a slab-wise partition;
 // the piece list is indexed from the launch's first region)
-template <class R>
+template <class R, bool PK = false>
 DK_SEG_KERNEL
 seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int blk_shift, uint64_t seg_base)
 {
@@ -152,12 +156,14 @@ seg_insert_kernel(unsigned long long *filter, PieceList<R> pl, int n_hashes, int
     constexpr int UNROLL = 8;
     uint64_t h[UNROLL];
     bool have[UNROLL];
+    const uint64_t region = seg_id >> pl.sbits, prefix = PK ? (pl.pk_region0 + region) << (64 - pl.pk_bits) : 0;
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
-            h[u] = sp.at(have[u] ? i : 0).h;
+            if constexpr (PK) h[u] = packed_load(pl.recs, region, pl.piece_cap, have[u] ? i : 0, prefix);
+            else h[u] = sp.at(have[u] ? i : 0).h;
         }
     };
     fetch(0);
@@ -201,24 +207,6 @@ struct MissOut {
 constexpr int MAX_SUB_BITS = 10;
 constexpr int SUB_TALLY = 1 << MAX_SUB_BITS;       // index of the batch's absent tally behind the units' fills
 constexpr int ACC_NONE = 0, ACC_PLAIN = 1, ACC_PACKED = 2;
-
-// Packed unit store (k <= 32, units of >= 16 implied prefix bits, i.e. every accumulator of a set of 2^28 bits or more):
-// all records of unit u share the top T + u bits of their hash, so only the low 48 bits are kept -- 6 bytes per
-// record instead of 8.  A unit of `cap` records is cap x u32 (hash bits 0..31) followed by cap x u16 (bits 32..47):
-// both arrays stay naturally aligned and every load / store instruction of a wave touches consecutive addresses.
-constexpr int PACKED_REC_BYTES = 6;
-constexpr int PACKED_MIN_PREFIX_BITS = 16;
-__device__ __forceinline__ void packed_store(void *store, uint64_t unit, uint32_t cap, uint32_t pos, uint64_t h)
-{
-    char *base = (char *)store + unit * (uint64_t)cap * PACKED_REC_BYTES;
-    ((uint32_t *)base)[pos] = (uint32_t)h;
-    ((uint16_t *)(base + (uint64_t)cap * 4))[pos] = (uint16_t)(h >> 32);
-}
-__device__ __forceinline__ uint64_t packed_load(const void *store, uint64_t unit, uint32_t cap, uint32_t pos, uint64_t prefix)
-{
-    const char *base = (const char *)store + unit * (uint64_t)cap * PACKED_REC_BYTES;
-    return prefix | ((uint64_t)((const uint16_t *)(base + (uint64_t)cap * 4))[pos] << 32) | ((const uint32_t *)base)[pos];
-}
 
 template <class R, int ACC>
 struct MissSink {
@@ -297,7 +285,7 @@ __device__ __forceinline__ bool batch_has_failed(const Counters *ctr)
 
 // NH > 0: the number of hash bits is a compile-time constant (the four LDS reads of a record are then
 // issued back to back instead of one by one behind the short-circuit test); NH == 0: n_hashes at run time
-template <class R, int NH, int ACC>
+template <class R, int NH, int ACC, bool PK = false>
 DK_SEG_KERNEL
 seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl, int n_hashes, int blk_shift,
                  uint64_t seg_base, MissOut<R> mo, Counters *ctr)
@@ -323,6 +311,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
     // records per segment -- a whole-genome batch against 2^19 segments -- more than half of the 8192 slots of an iteration
     // are empty, and the tests of an empty slot cost what those of a record cost.
     const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x);
+    const uint64_t region = seg_id >> pl.sbits, prefix = PK ? (pl.pk_region0 + region) << (64 - pl.pk_bits) : 0;
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
@@ -330,7 +319,8 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
             if (i0 + (uint32_t)u * SEG_THREADS + wave_first >= n) break;
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
-            rec[u] = sp.at(have[u] ? i : 0);
+            if constexpr (PK) rec[u].h = packed_load(pl.recs, region, pl.piece_cap, have[u] ? i : 0, prefix);
+            else rec[u] = sp.at(have[u] ? i : 0);
         }
     };
     fetch(0);
@@ -375,7 +365,7 @@ seg_probe_kernel(const unsigned long long *__restrict__ filter, PieceList<R> pl,
 
 // ---- exact set: the segment is an open-addressing table (dk_device.h) -----------------------------
 // Same shape as seg_insert / seg_probe: segment -> LDS, one LDS operation chain per record, segment back.
-template <class R>
+template <class R, bool PK = false>
 DK_SEG_KERNEL
 seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Counters *ctr, uint64_t seg_base)
 {
@@ -391,12 +381,14 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
     constexpr int UNROLL = 8;
     R rec[UNROLL];
     bool have[UNROLL];
+    const uint64_t region = seg_id >> pl.sbits, prefix = PK ? (pl.pk_region0 + region) << (64 - pl.pk_bits) : 0;
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
-            rec[u] = sp.at(have[u] ? i : 0);
+            if constexpr (PK) rec[u].h = packed_load(pl.recs, region, pl.piece_cap, have[u] ? i : 0, prefix);
+            else rec[u] = sp.at(have[u] ? i : 0);
         }
     };
     fetch(0);
@@ -425,7 +417,7 @@ seg_exact_insert_kernel(unsigned long long *table, PieceList<R> pl, int T, Count
 // walk over the segments with the table and the records fetched in one round trip measured 6.8 ms
 // against 5.1 ms for this form at 2^17 segments: the hardware's workgroup scheduler overlaps the
 // segments' load / probe phases better than two resident persistent workgroups per CU do.)
-template <class R, int ACC>
+template <class R, int ACC, bool PK = false>
 DK_SEG_KERNEL
 seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R> pl, int T, uint64_t seg_base,
                        MissOut<R> mo, Counters *ctr)
@@ -446,12 +438,14 @@ seg_exact_probe_kernel(const unsigned long long *__restrict__ table, PieceList<R
     constexpr int UNROLL = 8;
     R rec[UNROLL];
     bool have[UNROLL];
+    const uint64_t region = seg_id >> pl.sbits, prefix = PK ? (pl.pk_region0 + region) << (64 - pl.pk_bits) : 0;
     auto fetch = [&](uint32_t i0) {
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
             const uint32_t i = i0 + (uint32_t)u * SEG_THREADS + threadIdx.x;
             have[u] = i < n;
-            rec[u] = sp.at(have[u] ? i : 0);
+            if constexpr (PK) rec[u].h = packed_load(pl.recs, region, pl.piece_cap, have[u] ? i : 0, prefix);
+            else rec[u] = sp.at(have[u] ? i : 0);
         }
     };
     fetch(0);

@@ -54,6 +54,7 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
         for smp in (0, 1):
             pb = d.ReadBatch.synth(eng, gcfg, smp, 0, n_parent)
             eng.set_option("mode", 2)
+            eng.set_option("l2_packed", smp)               # the second parent through the packed-region kernels
             ks.insert_reads(pb)
             names = [n for n, _ in eng.timings()["stages"]]
             assert names[:3] == ["scan_part", "repart", "seg_insert"] and "overflow_redo" not in names, names
@@ -70,6 +71,7 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
         del fd, kd
         torch.cuda.empty_cache()
         eng.set_option("mode", 0)
+        eng.set_option("l2_packed", 0)
         # ---- the whole child through the direct family (one dk_probe per batch, merged) = the reference table ------
         eng.set_option("mode", 1)
         parts = [d.KmerCounter(eng).child_only(d.ReadBatch.synth(eng, gcfg, 2, b * n_child, n_child), ks) for b in range(2)]
@@ -87,8 +89,9 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
         eng.set_option("mode", 2)
         # ---- accumulate: one window (6-byte packed units, the shape of configs[2] now and of a configs[3] rank),
         #      two windows (round 2's pass), and one window over the 512 x 1024 + sub-segment-split layout of round 2 ----
-        for windows, scan_bits in ((1, 0), (2, 0), (1, 9)):
+        for windows, scan_bits, l2_packed in ((1, 0, 0), (2, 0, 0), (1, 9, 0), (1, 0, 1), (2, 9, 1)):
             eng.set_option("scan_bits", scan_bits)
+            eng.set_option("l2_packed", l2_packed)     # 6-byte records in the level-2 regions too (off by default: slower)
             acc = d.ChildAccumulator(eng, ks, capacity_records=int(0.2 * 2 * n_child * 120 / windows), window_count=windows)
             n_units, cap, rb = acc.geometry()
             assert rb == 6
@@ -115,6 +118,7 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
             assert _sum_checksums(cs2) == want2[0], (windows, scan_bits)
             acc.close()
         eng.set_option("scan_bits", 0)
+        eng.set_option("l2_packed", 0)
         # ---- the oracle on a subset, against the downloaded 64-GiB filter ------------------------------------------
         filt = ks.to_host()
         assert int(np.bitwise_count(filt[:1 << 20]).sum()) > 0
