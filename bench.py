@@ -80,8 +80,10 @@ def stage_algorithmic_bytes(stage, st, filter_bytes, rec_bytes, windows=1):
     return table.get(stage)
 
 
-def roofline_of(stage_ms, stage_bytes, traffic_by_kernel, traffic_source):
-    """roofline object of the pass: the dominant kernel on top, every stage under "stages", the pass total"""
+def roofline_of(stage_ms, stage_bytes, traffic_by_kernel, traffic_source, launches=None):
+    """roofline object of the pass: the dominant kernel on top, every stage under "stages", the pass total.
+    launches: stage -> kernel launches per step (slab-wise stages: one per level-2 slab); bytes and time are those of the
+    stage's launches of one step together, and achieved = bytes / time is the same per launch or per step"""
     stages = {}
     for name, ms in stage_ms.items():
         b = stage_bytes.get(name)
@@ -94,8 +96,12 @@ def roofline_of(stage_ms, stage_bytes, traffic_by_kernel, traffic_source):
     tot_ms = sum(v["ms"] for v in timed.values())
     out = {"bound": "hbm", "kernel": dom, "achieved": timed[dom]["achieved"] if dom else None, "peak": HBM_PEAK_GBS,
            "unit": "GB/s", "frac": timed[dom]["frac"] if dom else None,
-           "traffic": (traffic_by_kernel or {}).get(dom), "traffic_source": traffic_source,
-           "algorithmic_bytes_per_launch": timed[dom]["algorithmic_bytes"] if dom else None,
+           "traffic": ((traffic_by_kernel or {}).get(dom) or 0) / (launches or {}).get(dom, 1) or None,
+           "traffic_per_step": (traffic_by_kernel or {}).get(dom), "traffic_source": traffic_source,
+           "launches_per_step": (launches or {}).get(dom, 1) if dom else None,
+           "algorithmic_bytes_per_launch": timed[dom]["algorithmic_bytes"] / (launches or {}).get(dom, 1) if dom else None,
+           "kernel_ms_per_launch": timed[dom]["ms"] / (launches or {}).get(dom, 1) if dom else None,
+           "algorithmic_bytes_per_step": timed[dom]["algorithmic_bytes"] if dom else None,
            "kernel_ms": timed[dom]["ms"] if dom else None,
            "stages": stages,
            "pass": {"algorithmic_bytes": tot_b, "ms": tot_ms, "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
@@ -114,7 +120,8 @@ def committed_traffic(workload, reads, log2_bits, world):
         tj = json.load(open(prof))
         entry = tj.get("workloads", {}).get(workload) or (tj if workload == "chr20" else None)
         if entry and entry.get("reads") == reads and entry.get("log2_bits") == log2_bits:
-            return ({k: v.get("hbm_bytes_per_launch") for k, v in entry.get("kernels", {}).items()},
+            # (a slab-wise stage launches its kernel once per slab: the stage's traffic is that of all its launches of a step)
+            return ({k: v.get("hbm_bytes_per_step", v.get("hbm_bytes_per_launch")) for k, v in entry.get("kernels", {}).items()},
                     "profiles/traffic.json (static: committed rocprofv3 --pmc passes of this workload, not this run)")
     except Exception:
         pass
@@ -263,6 +270,8 @@ def main():
     ap.add_argument("--no-reserve", action="store_true", help="wgs: no arena (dk_engine_reserve): the grow-only pool allocates inside the first batches")
     ap.add_argument("--no-other-workloads", action="store_true", help="wgs, one GPU: skip the short chr20 / ont runs attached under other_workloads")
     ap.add_argument("--other-steps", type=int, default=4, help="timed steps of each of the other workloads")
+    ap.add_argument("--no-ingest", action="store_true", help="wgs, one GPU: skip the PCIe-inclusive steps (batches uploaded from pinned host memory)")
+    ap.add_argument("--ingest-steps", type=int, default=6, help="steps of the PCIe-inclusive measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the N>1 path on a box with fewer GPUs than ranks (collectives staged through the host)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -462,6 +471,7 @@ def main():
             dist.all_reduce(bt, op=dist.ReduceOp.MIN)
             batch = int(bt.item())
         n_batches = (reads_rank + batch - 1) // batch
+        batch = (reads_rank + n_batches - 1) // n_batches      # equal batches (no short last one: 150 M reads per rank = 4 x 37.5 M)
         set_hint(batch)
         room = free_bytes() - later - slab_room - batch * (ws_per_read - 57) / R
         n_res = int(max(n_keep, min(n_batches, args.warmup + args.steps, room // (batch * 57))))
@@ -512,7 +522,7 @@ def main():
         for i in range(args.steps):
             j = args.warmup + i
             st = acc.add(resident[j % n_res])
-            step_stats = st
+            step_stats = st if step_stats is None else {key: step_stats[key] + st[key] for key in st}
             windows_timed += st["n_windows"]
             t = eng.timings()
             total_dev_ms += t["total_ms"]
@@ -535,6 +545,7 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         windows_done = windows_timed / R                     # a step completes 1/R of its batch's membership work
+        step_stats = {key: v / args.steps for key, v in step_stats.items()}      # the average step (batches may differ in size)
         for rb in resident:
             rb.close()
     else:
@@ -632,9 +643,67 @@ def main():
                "note": "read generation (synthetic, on the GPU) is inside child_seconds / parent_seconds and subtracted for child_gkmers_s; "
                        + ("the ranks swap accumulator unit ranges before counting (dist.accum_exchange_finish): counts are exact across "
                           "the read shards, every rank keeps its share of the hash space" if world > 1 else "one GPU")}
+    ingest = None
     if wgs:
         acc_rec_bytes = acc.geometry()[2]
         timed_slabs = eng.info("plan_slabs")
+        if world == 1 and not args.no_ingest and args.ingest_steps > 0:
+            # PCIe-inclusive rate (reported beside `value`, never instead of it): the same steps with every batch arriving from
+            # pinned host memory -- the upload of batch i + 1 (dk_reads_from_packed_async, copy stream) overlaps the kernels of
+            # batch i.  Three host buffers hold three different batches; the accumulator starts empty.
+            progress("ingest from the host: %d steps" % args.ingest_steps)
+            n_host = min(3, n_batches)
+            host, meta = [], []
+            for b in range(n_host):
+                lo, n = batch_range(b)
+                rb = dk.ReadBatch.synth(eng, gcfg, 2, lo, n)
+                bases, mask, n_bases = rb.download()
+                pp = dk.PinnedPacked(n_bases)
+                pp.bases[:] = bases
+                pp.mask[:] = mask
+                host.append(pp)
+                meta.append((n_bases, n, rb.stats()["n_windows"]))
+                rb.close()
+                del bases, mask
+            acc.reset(0)
+            # one untimed step (the copy stream and its buffers come up), then the timed ones
+            w0 = dk.ReadBatch.from_packed_async(eng, host[0], *meta[0])
+            acc.add(w0)
+            w0.close()
+            acc.reset(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nxt = dk.ReadBatch.from_packed_async(eng, host[0], *meta[0])
+            up_bytes, in_windows, dev_ms = 0, 0, 0.0
+            for i in range(args.ingest_steps):
+                cur = nxt
+                if i + 1 < args.ingest_steps:
+                    nxt = dk.ReadBatch.from_packed_async(eng, host[(i + 1) % n_host], *meta[(i + 1) % n_host])
+                st = acc.add(cur)
+                dev_ms += eng.timings()["total_ms"]
+                cur.close()
+                in_windows += st["n_windows"]
+                up_bytes += (host[i % n_host].n_bwords + host[i % n_host].n_mwords) * 8
+            res = acc.finish(min_count=wl["min_count"])
+            dev_ms += eng.timings()["total_ms"]
+            res.close()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            # the same uploads alone (nothing to overlap with): what the link delivers
+            t1 = time.perf_counter()
+            for i in range(min(3, args.ingest_steps)):
+                rb = dk.ReadBatch.from_packed_async(eng, host[i % n_host], *meta[i % n_host])
+                rb.wait()
+                rb.close()
+            link_gbs = min(3, args.ingest_steps) * up_bytes / args.ingest_steps / (time.perf_counter() - t1) / 1e9
+            ingest = {"gkmers_s_pcie_inclusive": in_windows / R / dt / 1e9, "steps": args.ingest_steps, "ms_per_step": dt / args.ingest_steps * 1e3,
+                      "device_ms_per_step": dev_ms / args.ingest_steps, "bytes_uploaded_per_step": up_bytes / args.ingest_steps,
+                      "upload_alone_gbs": link_gbs, "reads_per_step": batch,
+                      "note": "packed reads (2-bit bases + 1-bit flags, 56.6 bytes per 150-bp read) in pinned host memory, uploaded with "
+                              "dk_reads_from_packed_async one batch ahead of the batch being accumulated; counting included; "
+                              "hash_windows > 1 would upload every batch once per window"}
+            for pp in host:
+                pp.close()
         acc.close()
     elif world > 1:
         # chr20 / ont over several GPUs, end to end: one more child pass per rank + the cross-rank sum of the per-rank
@@ -672,7 +741,8 @@ def main():
                 b = stage_algorithmic_bytes(n, finish_stats, filter_bytes, rec_bytes, R)
                 sb[n] = b / args.steps if b else None
         traffic, tsrc = committed_traffic(args.workload, wl["reads"], args.log2_bits, world)
-        rl = roofline_of(stages, sb, traffic, tsrc)
+        slab_launches = {n: timed_slabs for n in ("repart", "seg_probe", "seg_exact_probe")} if wgs else None
+        rl = roofline_of(stages, sb, traffic, tsrc, slab_launches)
         desc = {
             "wgs": "configs[2]: k=%d, full 30x WGS synthetic trio, %d x %d bp reads per sample (genome %.2f Gb), parent Bloom 2^%d bits "
                    "(%d GiB) resident in HBM, child streamed in %d-read batches through %d hash-window passes (dk_accum_add), "
@@ -728,6 +798,8 @@ def main():
             out["finish_stats"] = finish_stats
         if e2e:
             out["end_to_end"] = e2e
+        if ingest:
+            out["ingest_host"] = ingest
         if world > 1 and wgs:
             out["config"]["accumulator_exchange"] = ("dk_accum_exchange_finish (RCCL, in place)" if native else "torch.distributed (rehearsal / fallback)")
             out["config"]["accumulator_exchange_bytes_sent_rank0"] = exchange_bytes[0]

@@ -7,7 +7,7 @@ ARGS=$1; shift
 mkdir -p gpurun_out
 for round in 1 2; do
   for O in "$@"; do
-    timeout -k 10 400 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads $ARGS $O > gpurun_out/ab.log 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
+    timeout -k 10 400 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads --no-ingest $ARGS $O > gpurun_out/ab.log 2> gpurun_out/ab.err || { tail -5 gpurun_out/ab.err; exit 1; }
     python - "$O" <<'PY'
 import json, sys
 line = [l for l in open("gpurun_out/ab.log") if l.startswith("{")][0]

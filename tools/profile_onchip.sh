@@ -9,7 +9,7 @@ shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT gpurun_out/profiles_$TAG
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end $*"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads --no-ingest $*"
 i=0
 for set in "VALUBusy SALUBusy" "VALUUtilization LDSBankConflict" "MemUnitBusy MemUnitStalled" "WriteUnitStalled FetchSize"; do
     i=$((i + 1))

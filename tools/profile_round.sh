@@ -12,7 +12,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # BENCH: another driver script (tools/kmers_bench.py); default = bench.py in its profiling shape
-if [ -n "$BENCH" ]; then ARGS="$BENCH $*"; else ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end $*"; fi
+if [ -n "$BENCH" ]; then ARGS="$BENCH $*"; else ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-end-to-end --no-other-workloads --no-ingest $*"; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python3 $ARGS > $OUT/bench_under_stats.log 2> $OUT/bench_under_stats.err
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- python3 $ARGS > $OUT/bench_under_fetch.log 2> $OUT/bench_under_fetch.err

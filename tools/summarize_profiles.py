@@ -26,11 +26,16 @@ def short_name(kernel):
 LAST = 7      # the timed steps (and their warm-up) are the last launches of every kernel: bench.py --steps 5 --warmup 2
 
 
-def steady(ls, grid_of):
-    """the last LAST launches of a kernel's steady shape: of its final 3 * LAST launches, those with the grid of the larger
-    of the last two (a dk_probe step launches the membership kernel twice -- on 64 sampled segments, then on all)"""
+PER_STEP = {}     # kernel -> launches per step (slab-wise stages: one launch per level-2 slab), set from the bench line
+
+
+def steady(ls, grid_of, name=None):
+    """the launches of a kernel's last LAST steps in its steady shape: of its final 3 * LAST * per_step launches, those with
+    the grid of the larger of the last two (a dk_probe step launches the membership kernel twice -- on 64 sampled segments,
+    then on all); a slab-wise stage launches its kernel once per slab, PER_STEP[name] times per step"""
+    per = PER_STEP.get(name, 1)
     top = max(int(grid_of(x) or 0) for x in ls[-2:])
-    return [x for x in ls[-3 * LAST:] if int(grid_of(x) or 0) == top][-LAST:]
+    return [x for x in ls[-3 * LAST * per:] if int(grid_of(x) or 0) == top][-LAST * per:]
 
 
 def trace_summary(src, dst):
@@ -47,9 +52,11 @@ def trace_summary(src, dst):
     rows = []
     for name, ls in sorted(by.items()):
         ls.sort()
-        last = steady(ls, lambda x: x[2])
+        last = steady(ls, lambda x: x[2], name)
+        per = PER_STEP.get(name, 1)
         rows.append({"Kernel": name, "Calls": len(ls), "AverageNs_all": round(sum(x[1] for x in ls) / len(ls)),
                      "Last_launches": len(last), "AverageNs_last": round(sum(x[1] for x in last) / len(last)),
+                     "Launches_per_step": per, "Ns_per_step_last": round(sum(x[1] for x in last) / (len(last) / per)),
                      "Grid_Size_last": last[-1][2], "Workgroup_Size_last": last[-1][3]})
     with open(os.path.join(dst, "kernel_trace_summary.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
@@ -85,6 +92,10 @@ def main():
     line = bench_line(os.path.join(src, "bench_under_stats.log"))
     if line:
         json.dump(line, open(os.path.join(dst, "bench_line_under_profiler.json"), "w"))
+        slabs = int(line.get("config", {}).get("level2_slabs") or 1)
+        if line.get("config", {}).get("name") == "wgs" and slabs > 1:
+            for name in ("repart", "seg_probe", "seg_exact_probe"):
+                PER_STEP[name] = slabs
     lines = [l for l in open(os.path.join(src, "bench_under_stats.log")) if l.startswith("{")]
     if len(lines) > 1:                       # drivers that print one line per configuration (tools/kmers_bench.py)
         open(os.path.join(dst, "bench_lines_under_profiler.jsonl"), "w").writelines(lines)
@@ -116,14 +127,16 @@ def main():
     for name, c in per.items():
         if not c.get("FETCH_SIZE") or not c.get("WRITE_SIZE"):
             continue
-        f = [v for _, v in steady(c["FETCH_SIZE"], lambda x: x[0])]
-        wv = [v for _, v in steady(c["WRITE_SIZE"], lambda x: x[0])]
+        f = [v for _, v in steady(c["FETCH_SIZE"], lambda x: x[0], name)]
+        wv = [v for _, v in steady(c["WRITE_SIZE"], lambda x: x[0], name)]
         fm, wm = sum(f) / len(f), sum(wv) / len(wv)
+        per = PER_STEP.get(name, 1)
         traffic["kernels"][name] = {"fetch_bytes_corrected": fm * 1024 * 2, "write_bytes": wm * 1024,
                                     "hbm_bytes_per_launch": fm * 1024 * 2 + wm * 1024,
+                                    "launches_per_step": per, "hbm_bytes_per_step": (fm * 1024 * 2 + wm * 1024) * per,
                                     "fetch_size_raw_kib": fm, "write_size_raw_kib": wm, "launches_seen": min(len(f), len(wv))}
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-    print(json.dumps({k: round(v["hbm_bytes_per_launch"] / 1e9, 2) for k, v in traffic["kernels"].items()}))
+    print(json.dumps({k: round(v["hbm_bytes_per_step"] / 1e9, 2) for k, v in traffic["kernels"].items()}))
     for r in trows:
         print(r)
 
