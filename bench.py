@@ -650,9 +650,11 @@ def main():
         if world == 1 and not args.no_ingest and args.ingest_steps > 0:
             # PCIe-inclusive rate (reported beside `value`, never instead of it): the same steps with every batch arriving from
             # pinned host memory -- the upload of batch i + 1 (dk_reads_from_packed_async, copy stream) overlaps the kernels of
-            # batch i.  Three host buffers hold three different batches; the accumulator starts empty.
+            # batch i.  Every step brings a different batch (one pinned host buffer each: a batch met twice would make every
+            # absent k-mer a duplicate, which is not what a sample looks like); the accumulator starts empty.
+            args.ingest_steps = min(args.ingest_steps, n_batches)
             progress("ingest from the host: %d steps" % args.ingest_steps)
-            n_host = min(3, n_batches)
+            n_host = args.ingest_steps
             host, meta = [], []
             for b in range(n_host):
                 lo, n = batch_range(b)
@@ -681,6 +683,8 @@ def main():
                     nxt = dk.ReadBatch.from_packed_async(eng, host[(i + 1) % n_host], *meta[(i + 1) % n_host])
                 st = acc.add(cur)
                 dev_ms += eng.timings()["total_ms"]
+                ingest_stages = {nm: round(ms, 2) for nm, ms in eng.timings()["stages"]}
+                progress("ingest step %d: %s" % (i, ingest_stages))
                 cur.close()
                 in_windows += st["n_windows"]
                 up_bytes += (host[i % n_host].n_bwords + host[i % n_host].n_mwords) * 8
@@ -698,7 +702,7 @@ def main():
             link_gbs = min(3, args.ingest_steps) * up_bytes / args.ingest_steps / (time.perf_counter() - t1) / 1e9
             ingest = {"gkmers_s_pcie_inclusive": in_windows / R / dt / 1e9, "steps": args.ingest_steps, "ms_per_step": dt / args.ingest_steps * 1e3,
                       "device_ms_per_step": dev_ms / args.ingest_steps, "bytes_uploaded_per_step": up_bytes / args.ingest_steps,
-                      "upload_alone_gbs": link_gbs, "reads_per_step": batch,
+                      "upload_alone_gbs": link_gbs, "reads_per_step": batch, "stages_ms_of_the_last_step": ingest_stages,
                       "note": "packed reads (2-bit bases + 1-bit flags, 56.6 bytes per 150-bp read) in pinned host memory, uploaded with "
                               "dk_reads_from_packed_async one batch ahead of the batch being accumulated; counting included; "
                               "hash_windows > 1 would upload every batch once per window"}

@@ -50,6 +50,14 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     const uint32_t region = blockIdx.x % RESULT_REGIONS;
     unsigned long long *fill = &ctr->region_fill[region];
     const uint64_t region_base = (uint64_t)region * region_cap;
+    // Which round of the table phase a key belongs to: 20 hash bits ABOVE the table's slot bits (8..18) and BELOW the unit's
+    // common prefix -- k <= 32 keys are the hashes themselves, and all hashes of a unit share their top T bits.  (Taken from
+    // bits 36..55, as until round 3, the selector was constant within a unit for T > 8 + 20: every split of a crowded round
+    // put all keys into one sub-round again, the rounds multiplied to 4096 and more, each a pass over the unit -- a unit whose
+    // records are mostly duplicates, e.g. a sample seen twice, took 6 ms instead of 20 us: 3 s against 12 ms for 2 x 10^9 records.)
+    auto round_of = [](unsigned long long f, uint32_t n_rounds) -> uint32_t {
+        return (uint32_t)((((f >> 19) & 0xFFFFF) * (uint64_t)n_rounds) >> 20);
+    };
     auto fp_of = [](const R &rec) -> unsigned long long {
         if constexpr (WIDE) {
             const unsigned long long f = fmix64(rec.h ^ (rec_hi(rec) * 0x9E3779B97F4A7C15ULL));
@@ -252,7 +260,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                             bool want = have(0, u) && flagged(u, hv[u]);
                             if (want && rounds > 1) {
                                 const unsigned long long fu = fp_of(hv[u]);
-                                want = (uint32_t)((((fu >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20) == r;
+                                want = round_of(fu, rounds) == r;
                             }
 #pragma unroll
                             for (uint32_t part = 0; part < 64 / WB; part++) {          // at most WB records join at a time
@@ -275,7 +283,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                             const R rec = hv[u];
                             if (!flagged(u, rec)) continue;
                             const unsigned long long f = fp_of(rec);
-                            const uint32_t rr = (uint32_t)((((f >> 36) & 0xFFFFF) * (uint64_t)rounds) >> 20);
+                            const uint32_t rr = round_of(f, rounds);
                             if (rr != r) continue;
                             uint32_t slot = (uint32_t)(f >> 8) & slot_mask;
                             uint32_t tries = 0;

@@ -226,3 +226,31 @@ def test_batches_uploaded_while_the_previous_one_is_probed_give_the_oracle_resul
             ks.close()
             for pp in pinned:
                 pp.close()
+
+
+def test_counting_a_sample_of_duplicates_does_not_fall_off_a_cliff():
+    """every absent k-mer twice (a batch accumulated twice) against a 2^36-bit set: all records take the table path of
+    seg_count and its crowded rounds split.  The split must spread the keys (until round 3 the round selector used hash
+    bits that are constant inside a unit of a large set: the rounds multiplied 4096-fold and this count took seconds)"""
+    d = dk()
+    n = 2_000_000
+    gcfg = d.synth_config(genome_len=64 << 20)
+    with d.Engine(k=31, filter_log2_bits=36, n_hashes=4, seed=1, mode="bucketed") as eng:
+        ks = d.KmerSet(eng)
+        for smp in (0, 1):
+            ks.insert_reads(d.ReadBatch.synth(eng, gcfg, smp, 0, n))
+        rb = d.ReadBatch.synth(eng, gcfg, 2, 0, n)
+        acc = d.ChildAccumulator(eng, ks, capacity_records=int(0.5 * n * 120))
+        acc.add(rb)
+        once = acc.finish(min_count=1)
+        t_once = dict(eng.timings()["stages"])["seg_count"]
+        acc.add(rb)
+        twice = acc.finish(min_count=1)
+        t_twice = dict(eng.timings()["stages"])["seg_count"]
+        (h1, l1, c1), (h2, l2, c2) = once.to_host(), twice.to_host()
+        assert np.array_equal(l1, l2) and np.array_equal(h1, h2) and np.array_equal(2 * c1, c2)
+        assert t_twice < 40 * max(t_once, 0.5), (t_once, t_twice)
+        for r in (once, twice):
+            r.close()
+        acc.close()
+        ks.close()
