@@ -728,6 +728,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"cnt_split_to", &dk_options::cnt_split_to, 0, 1 << 30},
         {"sub_split", &dk_options::sub_split, 0, 9},
         {"repart_plain", &dk_options::repart_plain, 0, 1},
+        {"repart_pieces", &dk_options::repart_pieces, 0, 2},
         {"repart_bits", &dk_options::repart_bits, 0, 10},
         {"scan_bits", &dk_options::scan_bits, 0, 10},
         {"slabs", &dk_options::slabs, 0, 1024},

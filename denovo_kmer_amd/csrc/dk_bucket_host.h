@@ -243,7 +243,27 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
             B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
             p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \
     } while (0)
-    if constexpr (WIDE) DK_REPART_LAUNCH(512, 8, 8);
+    // The pieces of a bin read as one array (full tiles) where tiles cut piece by piece would be poorly filled: the
+    // concatenating kernel costs ~6 % more per tile (prefix sum of the piece sizes, bisection), so it is taken when the
+    // piece-wise launch would provide more than 1.25 times the tile capacity the records need (whole-genome child step,
+    // 22 K-record pieces in four 8 K tiles: repart 21.6 -> 20.4 ms; parent batch, 59 K-record pieces in eight: 50.7 -> 54.0,
+    // so it stays piece-wise).  Option "repart_pieces": 1 = always piece-wise, 2 = always concatenated.
+    const uint64_t mean_bin = p.n_max / p.p1;
+    const uint32_t tile_recs = WIDE ? 512 * 8 : 1024 * 8;
+    const uint64_t launched = (uint64_t)((p.capw + tile_recs - 1) / tile_recs) * tile_recs * p.G;
+    const bool concat = p.G >= 2 && p.G <= 512 && e->opt.repart_pieces != 1 &&
+                        (e->opt.repart_pieces == 2 || launched * 4 > mean_bin * 5);
+#define DK_REPART_CONCAT(TH, PT, W)                                                                       \
+    do {                                                                                                  \
+        const uint32_t tpb = (uint32_t)((mean_bin + mean_bin / 12) / (TH * PT)) + 2;                        \
+        repart_kernel<TH, PT, W, R, false, true><<<repart_grid(tpb, p.slab_bins), TH, 0, e->stream>>>(     \
+            B.a, B.cnt1, p.G, p.capw, tpb, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \
+    } while (0)
+    if (concat && !p.packed2 && !(e->opt.repart_variant == 1 && !WIDE)) {
+        if constexpr (WIDE) DK_REPART_CONCAT(512, 8, 8);
+        else DK_REPART_CONCAT(1024, 8, 8);
+    } else if constexpr (WIDE) DK_REPART_LAUNCH(512, 8, 8);
     else if (p.packed2) {
         const uint32_t tpp = (p.capw + 1024 * 8 - 1) / (1024 * 8);
         repart_kernel<1024, 8, 8, R, true><<<repart_grid(p.G * tpp, p.slab_bins), 1024, 0, e->stream>>>(
@@ -251,6 +271,7 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
     } else if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
     else DK_REPART_LAUNCH(1024, 8, 8);
 #undef DK_REPART_LAUNCH
+#undef DK_REPART_CONCAT
 }
 
 // scan_part + repart (+ repart): afterwards B.rec / B.cursor2 hold every record of the batch (of the hash window

@@ -11,7 +11,12 @@ namespace dk {
 // which measured faster than private level-2 pieces; the cursor atomics are issued before the
 // scatter phase and only waited for after it, so their latency is covered.
 // PK (k <= 32, regions of >= 16 prefix bits): the regions receive packed 6-byte records (dk_bucket_common.h)
-template <int THREADS, int PER_THREAD, int MIN_WAVES, class R, bool PK = false>
+// CONCAT (level 2 over the scan's pieces, G <= 512): the G pieces of a bin are read as ONE array -- tile t of the bin is
+// records [t * TILE, (t + 1) * TILE) of their concatenation, found through a prefix sum of the piece sizes -- so every tile
+// but a bin's last is full; `tiles_per_piece` then is the number of tiles launched per BIN (the bin's last workgroup walks
+// whatever lies beyond).  Piece by piece, a 22 K-record piece filled its three 8 K tiles to 90 % and launched a fourth that
+// returned at once (whole-genome child step: 1024 bins x 256 pieces).
+template <int THREADS, int PER_THREAD, int MIN_WAVES, class R, bool PK = false, bool CONCAT = false>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
@@ -25,7 +30,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     __shared__ SplitLds<THREADS, PER_THREAD, R, NB, false> L;
     const int tid = (int)threadIdx.x;
     // one-dimensional grid (the number of bins can exceed the 65535 of grid.y): bin-major, then piece, then tile
-    const uint32_t per_bin = G * tiles_per_piece;
+    const uint32_t per_bin = CONCAT ? tiles_per_piece : G * tiles_per_piece;
     uint32_t b = blockIdx.x / per_bin, bx = blockIdx.x % per_bin;
     if (xcd_affine) {
         // eight bins at a time, one per XCD (consecutive blocks are dealt round-robin over the XCDs): all tiles of a bin
@@ -35,22 +40,65 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         bx = slot % per_bin;
     }
     b += bin0;
-    const uint32_t w = bx / tiles_per_piece, t0 = (bx % tiles_per_piece) * TILE;
-    const uint64_t piece = (uint64_t)b * G + w;
-    uint32_t n = cnt1[piece];
-    if (n > capw) n = capw;
+    __shared__ uint32_t pstart[CONCAT ? 513 : 1];        // CONCAT: first record of every piece in the bin's concatenation
+    __shared__ uint32_t pscan[CONCAT ? 17 : 1];
+    uint32_t n, t0;
+    const R *src = nullptr;
+    if constexpr (CONCAT) {
+        uint32_t c = 0;
+        if ((uint32_t)tid < G) {
+            c = cnt1[(uint64_t)b * G + tid];
+            if (c > capw) c = capw;
+        }
+        const uint32_t ex = block_excl_scan(c, pscan, &pscan[16]);
+        if ((uint32_t)tid < G) pstart[tid] = ex;
+        if (tid == 0) pstart[G] = pscan[16];
+        __syncthreads();
+        n = pstart[G];
+        t0 = bx * TILE;
+    } else {
+        const uint32_t w = bx / tiles_per_piece;
+        t0 = (bx % tiles_per_piece) * TILE;
+        const uint64_t piece = (uint64_t)b * G + w;
+        n = cnt1[piece];
+        if (n > capw) n = capw;
+        src = in + piece * capw + (uint64_t)b * bin_skew;
+    }
     if (t0 >= n) return;
     const int nbins = 1 << b2;
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
+  for (;;) {                                             // (one pass; CONCAT: the bin's last workgroup takes the tiles beyond the grid)
     for (int i = tid; i < NB; i += THREADS) L.cnt[i] = 0;
     if (tid == 0) L.ovf_seen = 0;
-    const R *src = in + piece * capw + (uint64_t)b * bin_skew;
     R hs[PER_THREAD];
+    if constexpr (CONCAT) {
+        // piece of the thread's first record by bisection, of the later ones (1024 records further each) by stepping on
+        const R *bin_base = in + (uint64_t)b * G * capw + (uint64_t)b * bin_skew;
+        uint32_t w = 0;
+        {
+            const uint32_t r0 = t0 + tid < n ? t0 + tid : 0;
+            uint32_t lo = 0, hi = G;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (pstart[mid] <= r0) lo = mid; else hi = mid;
+            }
+            w = lo;
+        }
 #pragma unroll
-    for (int j = 0; j < PER_THREAD; j++) {
-        const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
-        hs[j] = src[i < n ? i : 0];
+        for (int j = 0; j < PER_THREAD; j++) {
+            const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+            const uint32_t r = i < n ? i : 0;
+            if (r == 0) w = 0;
+            while (w + 1 < G && pstart[w + 1] <= r) w++;
+            hs[j] = bin_base[(uint64_t)w * capw + (r - pstart[w])];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER_THREAD; j++) {
+            const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
+            hs[j] = src[i < n ? i : 0];
+        }
     }
     __syncthreads();
     uint32_t valid = 0;
@@ -126,6 +174,11 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
         atomicMax(&ctr->fail_mark, 0xFFFFFFFFULL - slab);     // the first slab that lost records (slab-wise accumulate: redone exactly)
     }
+    if (!CONCAT || bx != per_bin - 1) break;
+    t0 += TILE;                                            // CONCAT, last workgroup of the bin: a bin larger than the grid allowed for
+    if (t0 >= n) break;
+    __syncthreads();
+  }
 }
 
 }  // namespace dk

@@ -52,6 +52,7 @@ struct dk_options {
     int l2_packed = 0;            // 1 = level-2 regions of >= 16 prefix bits hold packed 6-byte records (slower: DESIGN.md section 9; A/B runs, tests)
     int accum_plain = 0;          // dk_accum_create: 1 = never use packed 6-byte unit records (A/B runs, tests)
     int scan_bits = 0;            // scan_part: most hash bits level 1 may take (default 10; 9 = round 2's limit, for A/B runs)
+    int repart_pieces = 0;        // repart: 0 = automatic, 1 = one workgroup per tile of a PIECE (round 2), 2 = tiles over a bin's concatenated pieces
     int repart_plain = 0;         // repart: 1 = tiles in plain block order instead of one bin per XCD (A/B runs)
     int sub_split = 0;            // sub-segment split of the set kernels: 0 = automatic, 1..3 = force, 9 = never
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes

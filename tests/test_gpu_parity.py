@@ -707,6 +707,16 @@ def test_repart_in_plain_block_order_agrees():
     _forced_geometry_trio({"repart_plain": 1, "force_l3": 1}, ["scan_part", "repart", "repart3"])
 
 
+@pytest.mark.parametrize("repart_pieces", [1, 2])
+def test_repart_over_pieces_and_over_their_concatenation_agree(repart_pieces):
+    """repart reads a level-1 bin piece by piece (1) or as the concatenation of its pieces (2: full tiles; what the
+    whole-genome child step takes by itself); small batches leave pieces of a few records, many per tile -- with and
+    without a third level and a forced scan shape of many small workgroups (hundreds of pieces per bin)"""
+    _forced_geometry_trio({"repart_pieces": repart_pieces}, ["scan_part", "repart"])
+    _forced_geometry_trio({"repart_pieces": repart_pieces, "force_l3": 1}, ["scan_part", "repart", "repart3"])
+    _forced_geometry_trio({"repart_pieces": repart_pieces, "scan_variant": 5}, ["scan_part", "repart"])
+
+
 def test_forced_scan_shape_with_fewer_threads_than_bins():
     """variants 4 / 5 have 256 / 128 threads; with more level-1 bins than threads the plan moves bits to level 2
     (2^33 bits = 2^14 segments: b1_up pushes the level-1 split to 9 bits = 512 bins)"""

@@ -91,6 +91,7 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
         #      two windows (round 2's pass), and one window over the 512 x 1024 + sub-segment-split layout of round 2 ----
         for windows, scan_bits, l2_packed in ((1, 0, 0), (2, 0, 0), (1, 9, 0), (1, 0, 1), (2, 9, 1)):
             eng.set_option("scan_bits", scan_bits)
+            eng.set_option("repart_pieces", 2 if windows == 1 else 1)       # concatenated pieces / piece by piece
             eng.set_option("l2_packed", l2_packed)     # 6-byte records in the level-2 regions too (off by default: slower)
             acc = d.ChildAccumulator(eng, ks, capacity_records=int(0.2 * 2 * n_child * 120 / windows), window_count=windows)
             n_units, cap, rb = acc.geometry()
@@ -119,6 +120,7 @@ def test_configs2_geometry_insert_and_accumulate_against_oracle_and_direct_famil
             acc.close()
         eng.set_option("scan_bits", 0)
         eng.set_option("l2_packed", 0)
+        eng.set_option("repart_pieces", 0)
         # ---- the oracle on a subset, against the downloaded 64-GiB filter ------------------------------------------
         filt = ks.to_host()
         assert int(np.bitwise_count(filt[:1 << 20]).sum()) > 0
