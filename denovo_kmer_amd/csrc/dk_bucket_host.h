@@ -255,7 +255,7 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
                         (e->opt.repart_pieces == 2 || launched * 4 > mean_bin * 5);
 #define DK_REPART_CONCAT(TH, PT, W)                                                                       \
     do {                                                                                                  \
-        const uint32_t tpb = (uint32_t)((mean_bin + mean_bin / 12) / (TH * PT)) + 2;                        \
+        const uint32_t tpb = (uint32_t)(((uint64_t)p.G * p.capw + TH * PT - 1) / (TH * PT));               \
         repart_kernel<TH, PT, W, R, false, true><<<repart_grid(tpb, p.slab_bins), TH, 0, e->stream>>>(     \
             B.a, B.cnt1, p.G, p.capw, tpb, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
             p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \

@@ -13,9 +13,10 @@ namespace dk {
 // PK (k <= 32, regions of >= 16 prefix bits): the regions receive packed 6-byte records (dk_bucket_common.h)
 // CONCAT (level 2 over the scan's pieces, G <= 512): the G pieces of a bin are read as ONE array -- tile t of the bin is
 // records [t * TILE, (t + 1) * TILE) of their concatenation, found through a prefix sum of the piece sizes -- so every tile
-// but a bin's last is full; `tiles_per_piece` then is the number of tiles launched per BIN (the bin's last workgroup walks
-// whatever lies beyond).  Piece by piece, a 22 K-record piece filled its three 8 K tiles to 90 % and launched a fourth that
-// returned at once (whole-genome child step: 1024 bins x 256 pieces).
+// but a bin's last is full; `tiles_per_piece` then is the number of tiles launched per BIN (enough for G full pieces: a
+// bin cannot hold more; the workgroups beyond the bin's records return after the prefix sum).  Piece by piece, a 22 K-record
+// piece filled its three 8 K tiles to 90 % and launched a fourth that returned at once (whole-genome child step: 1024 bins x
+// 256 pieces).
 template <int THREADS, int PER_THREAD, int MIN_WAVES, class R, bool PK = false, bool CONCAT = false>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
@@ -68,29 +69,33 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
     const int nbins = 1 << b2;
     const int shift = 64 - b1 - b2;
     auto bin_of = [=](uint64_t h) -> uint32_t { return (uint32_t)(h >> shift) & (uint32_t)(nbins - 1); };
-  for (;;) {                                             // (one pass; CONCAT: the bin's last workgroup takes the tiles beyond the grid)
     for (int i = tid; i < NB; i += THREADS) L.cnt[i] = 0;
     if (tid == 0) L.ovf_seen = 0;
     R hs[PER_THREAD];
     if constexpr (CONCAT) {
-        // piece of the thread's first record by bisection, of the later ones (1024 records further each) by stepping on
+        // piece of the thread's first record by bisection; the later ones lie THREADS records further each: at most one
+        // step on per record in the usual case (pieces of thousands of records), bisection again otherwise.  Positions
+        // beyond the bin's end read its last record (ignored below), which keeps the walk monotonic.
         const R *bin_base = in + (uint64_t)b * G * capw + (uint64_t)b * bin_skew;
-        uint32_t w = 0;
-        {
-            const uint32_t r0 = t0 + tid < n ? t0 + tid : 0;
+        auto bisect = [&](uint32_t r) -> uint32_t {
             uint32_t lo = 0, hi = G;
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (pstart[mid] <= r0) lo = mid; else hi = mid;
+                if (pstart[mid] <= r) lo = mid; else hi = mid;
             }
-            w = lo;
-        }
+            return lo;
+        };
+        uint32_t w = 0;
 #pragma unroll
         for (int j = 0; j < PER_THREAD; j++) {
             const uint32_t i = t0 + (uint32_t)j * THREADS + tid;
-            const uint32_t r = i < n ? i : 0;
-            if (r == 0) w = 0;
-            while (w + 1 < G && pstart[w + 1] <= r) w++;
+            const uint32_t r = i < n ? i : n - 1;
+            if (j == 0) {
+                w = bisect(r);
+            } else if (pstart[w + 1] <= r) {               // (pstart[G] = n > r: w + 1 <= G here)
+                w++;
+                if (pstart[w + 1] <= r) w = bisect(r);
+            }
             hs[j] = bin_base[(uint64_t)w * capw + (r - pstart[w])];
         }
     } else {
@@ -174,11 +179,6 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
         atomicMax(&ctr->fail_mark, 0xFFFFFFFFULL - slab);     // the first slab that lost records (slab-wise accumulate: redone exactly)
     }
-    if (!CONCAT || bx != per_bin - 1) break;
-    t0 += TILE;                                            // CONCAT, last workgroup of the bin: a bin larger than the grid allowed for
-    if (t0 >= n) break;
-    __syncthreads();
-  }
 }
 
 }  // namespace dk
