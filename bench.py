@@ -48,15 +48,17 @@ WORKLOADS = {
 }
 
 
-def stage_algorithmic_bytes(stage, st, filter_bytes, rec_bytes, windows=1):
+def stage_algorithmic_bytes(stage, st, filter_bytes, rec_bytes, windows=1, absent_rec_bytes=None):
     """Algorithmic HBM bytes one launch of `stage` must move.
     st: n_bases, n_valid (all valid windows), n_absent (absent ones inside the hash window), n_distinct, n_emitted;
-    windows: hash windows of the pass (records, filter share and absent records are 1/windows of the batch's)."""
+    windows: hash windows of the pass (records, filter share and absent records are 1/windows of the batch's);
+    absent_rec_bytes: bytes of an absent record where it differs from a partition record (packed accumulator units: 6)."""
     nb, na = st["n_bases"], st["n_absent"]
     nv = st["n_valid"] / windows                            # records of this pass
     nd, ne = st.get("n_distinct", 0), st.get("n_emitted", 0)
     fb = filter_bytes / windows
     R = float(rec_bytes)
+    RA = float(absent_rec_bytes or rec_bytes)
     stream = nb * 3 / 8.0                                   # 2-bit bases + 1-bit mask
     table = {
         # direct family
@@ -68,13 +70,13 @@ def stage_algorithmic_bytes(stage, st, filter_bytes, rec_bytes, windows=1):
         "scan_part": stream + R * nv,                       # read stream, write one record per k-mer of the window
         "repart": 2 * R * nv,                               # read + write every record once
         "repart3": 2 * R * nv,
-        "seg_probe": R * nv + fb + R * na,                  # records + one sweep of the filter share + absent records out
+        "seg_probe": R * nv + fb + RA * na,                 # records + one sweep of the filter share + absent records out
         "seg_insert": R * nv + 2.0 * fb,                    # records + filter read and written back
-        "seg_count": R * na + (R + 4) * ne,                 # absent records in, (k-mer, count) out
+        "seg_count": RA * na + (R + 4) * ne,                # absent records in, (k-mer, count) out
         "seg_count_dry": R * na,                            # sizing run of a min_count > 1 finish: records in, nothing out
         "count_split": 2 * R * na,
         # exact set (--set-kind exact): the segments are hash tables, swept exactly like the filter
-        "seg_exact_probe": R * nv + fb + R * na,
+        "seg_exact_probe": R * nv + fb + RA * na,
         "seg_exact_insert": R * nv + 2.0 * fb,
     }
     return table.get(stage)
@@ -450,10 +452,22 @@ def main():
         # hash-window passes: one -- the occurrences of the whole hash space fit beside the filter as 6-byte records (and the
         # multi-GPU exchange is in place, so N > 1 needs no second copy); --windows 2 = round 2's two passes
         R = args.windows or wl["windows"]
-        # expected absent occurrences per pass: windows with >= 1 error base (7 % above what this generator yields; units
-        # have 5 sigma of room on top and spill to an overflow list of capacity / 64 records)
+        # expected absent occurrences per pass: the absent rate of the child's first 4 M reads (what a host sees after its
+        # first batch), 3 % on top; units have 5 sigma of room above that and spill to an overflow list of capacity / 64
+        # records.  (The analytic bound -- windows with >= 1 error base -- is 7.6 % above what this generator yields: 7 GB
+        # of accumulator that the batch, i.e. the amortisation of the filter sweep, can use.)
+        pn = min(4_000_000, reads_rank)
+        pb = dk.ReadBatch.synth(eng, gcfg, 2, first, pn)
+        pr = dk.KmerCounter(eng).child_only(pb, kset)
+        absent_rate = pr.stats["n_absent"] / max(pr.stats["n_windows"], 1)
+        pr.close()
+        pb.close()
+        if world > 1:
+            ar = torch.tensor([absent_rate], dtype=torch.float64, device=sdev)
+            dist.all_reduce(ar, op=dist.ReduceOp.MAX)        # every rank must build the same accumulator
+            absent_rate = float(ar.item())
         p_err = 1.0 - (1.0 - wl["err"]) ** k
-        cap = int(1.0 * p_err * reads_rank * (L - k + 1) / R)
+        cap = int(min(1.03 * absent_rate, 1.0 * p_err + 0.01) * reads_rank * (L - k + 1) / R)
         acc = dk.ChildAccumulator(eng, kset, capacity_records=cap, window_index=0, window_count=R)
         # the counting pass's result table comes from the same memory (sized from the capacity: a sixteenth of cap / min_count
         # entries of 12 bytes, + slack); the torch.distributed fallback of the exchange receives a second copy of the store
@@ -738,11 +752,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = windows_all / elapsed / 1e9
         stages = {n: ms / args.steps for n, ms in stage_sum.items()}
-        sb = {n: stage_algorithmic_bytes(n, step_stats, filter_bytes, rec_bytes, R) for n in stages}
+        arb = acc_rec_bytes if wgs else None               # accumulate mode: the absent records are the accumulator's (6 bytes packed)
+        sb = {n: stage_algorithmic_bytes(n, step_stats, filter_bytes, rec_bytes, R, arb) for n in stages}
         if finish_stats:
             for n, ms in finish_stages.items():            # once per K steps: amortised per step like its time
                 stages[n] = ms / args.steps
-                b = stage_algorithmic_bytes(n, finish_stats, filter_bytes, rec_bytes, R)
+                b = stage_algorithmic_bytes(n, finish_stats, filter_bytes, rec_bytes, R, arb)
                 sb[n] = b / args.steps if b else None
         traffic, tsrc = committed_traffic(args.workload, wl["reads"], args.log2_bits, world)
         slab_launches = {n: timed_slabs for n in ("repart", "seg_probe", "seg_exact_probe")} if wgs else None
@@ -773,6 +788,7 @@ def main():
                        "level2_slabs": timed_slabs if wgs else eng.info("plan_slabs"), "level1_bits": eng.info("plan_b1"), "level2_bits": eng.info("plan_b2"),
                        "sub_segment_split_bits": eng.info("plan_sbits"),
                        "accumulator_record_bytes": acc_rec_bytes if wgs else None,
+                       "accumulator_capacity_records": cap if wgs else None, "absent_rate_of_first_reads": absent_rate if wgs else None,
                        "arena_bytes": reserved, "arena_reserve_seconds": reserve_s,
                        "device_bytes_peak_of_the_engine": eng.info("pool_bytes_peak"),
                        "parallelism": "reads sharded x%d, %s-all-reduce of parent set" % (world, "OR" if args.set_kind == "bloom" else "union")},

@@ -68,6 +68,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     };
     // persistent: a workgroup walks segments blockIdx.x, +gridDim.x, ... (launching one tiny
     // workgroup per segment cost ~50 ns of wall time each at 2^18 segments)
+    Stamps st;
     for (uint64_t seg_id = blockIdx.x; seg_id < n_seg; seg_id += gridDim.x) {
         const SegPieces<R> sp = seg_pieces(pl, seg_id);
         const uint32_t n = sp.total();
@@ -118,6 +119,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
         if (single) load_chunk(0);
         lds_barrier();
+        st.mark(0);                                   // (DK_STAMPS) bitmaps cleared, records in registers
         // pass 1: mark
         for (uint32_t c = 0; c < n_chunks; c++) {
             if (!single) load_chunk(c);
@@ -131,6 +133,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             }
         }
         lds_barrier();
+        st.mark(1);                                   // marked
         // pass 2: classify; per-wave count of provably unique records, block count of flagged ones
         uint32_t my_unique = 0, my_flagged = 0;
         for (uint32_t c = 0; c < n_chunks; c++) {
@@ -172,6 +175,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         n_distinct += (tid == 0) ? all_unique : 0;
         if (tid == 0) gbase = (emit_unique && all_unique) ? atomicAdd(fill, (unsigned long long)all_unique) : 0ULL;
         lds_barrier();
+        st.mark(2);                                   // classified, bases known, output reserved
         // pass 3: emit the unique records, each wave a contiguous run, compacted by ballot
         if (emit_unique && all_unique) {
             uint64_t o = gbase + wave_base;
@@ -340,7 +344,9 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             }
         }
         lds_barrier();
+        st.mark(3);                                   // unique records emitted, flagged ones counted and emitted
     }
+    st.flush(ctr, 4);
     n_distinct = (uint32_t)wave_sum(n_distinct);
     n_fail = (uint32_t)wave_sum(n_fail);
     if (lane_id() == 0) {
