@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 XGMI_LINK_GBS = 153.0          # per link, 7 links per GPU
 
 WORKLOADS = {
-    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=48_000_000, parent_batch=128_000_000, log2_bits=39, err=5e-3,
+    "wgs": dict(k=31, read_len=150, reads=1_200_000_000, batch=64_000_000, parent_batch=128_000_000, log2_bits=39, err=5e-3,
                 min_count=2, windows=1, cfg="configs[2]"),
     "chr20": dict(k=31, read_len=150, reads=12_800_000, batch=12_800_000, parent_batch=12_800_000, log2_bits=34, err=5e-3,
                   min_count=1, windows=1, cfg="configs[1]"),

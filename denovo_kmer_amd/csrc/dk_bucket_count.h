@@ -133,7 +133,6 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             }
         }
         lds_barrier();
-        st.mark(1);                                   // marked
         // pass 2: classify; per-wave count of provably unique records, block count of flagged ones
         uint32_t my_unique = 0, my_flagged = 0;
         for (uint32_t c = 0; c < n_chunks; c++) {
@@ -175,7 +174,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         n_distinct += (tid == 0) ? all_unique : 0;
         if (tid == 0) gbase = (emit_unique && all_unique) ? atomicAdd(fill, (unsigned long long)all_unique) : 0ULL;
         lds_barrier();
-        st.mark(2);                                   // classified, bases known, output reserved
+        st.mark(1);                                   // marked, classified, bases known, output reserved
         // pass 3: emit the unique records, each wave a contiguous run, compacted by ballot
         if (emit_unique && all_unique) {
             uint64_t o = gbase + wave_base;
@@ -199,6 +198,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 }
             }
         }
+        st.mark(2);                                   // unique records emitted
         // Flagged records: exact counts in the LDS hash table, one sub-range of the key space per
         // round.  The number of rounds starts from a guess (8 copies per key) and a round whose keys
         // do not fit is split in four and redone -- nothing of it has been emitted yet -- so a segment
@@ -344,7 +344,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             }
         }
         lds_barrier();
-        st.mark(3);                                   // unique records emitted, flagged ones counted and emitted
+        st.mark(3);                                   // flagged records counted and emitted
     }
     st.flush(ctr, 4);
     n_distinct = (uint32_t)wave_sum(n_distinct);
