@@ -342,7 +342,9 @@ def main():
     native_possible = world == 1 or (args.backend == "nccl" and not args.single_device)
     if wgs and not args.no_reserve and native_possible:
         free, _ = torch.cuda.mem_get_info(dev)
-        reserved = max(0, free - (5 << 30))              # torch keeps a few GB for digests / scalars
+        # torch keeps a few GB for digests / scalars; with several ranks two RCCL communicators (torch's for the scalars,
+        # the library's for the set and the accumulator) bring their own channel buffers
+        reserved = max(0, free - ((5 if world == 1 else 20) << 30))
         t0 = time.perf_counter()
         eng.reserve(reserved)
         reserve_s = time.perf_counter() - t0

@@ -738,6 +738,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"l2_packed", &dk_options::l2_packed, 0, 1},
         {"accum_min_u", &dk_options::accum_min_u, 0, 10},
         {"mode", &dk_options::mode, 0, 2},
+        {"kmers_plain", &dk_options::kmers_plain, 0, 1},
         {"merge_undersize", &dk_options::merge_undersize, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
@@ -1060,9 +1061,15 @@ dk_status dk_reads_kmers(dk_engine *e, const dk_reads *r, uint64_t *kmers_lo, ui
     if (st == DK_OK && r->n_bases) {
         const StreamView sv = view_of(r);
         const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)e->n_cu * 4);
-        if (wide)
+        if (wide && !e->opt.kmers_plain)
+            kmers_tile_kernel<KT, true, true><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
+                                                                          hi.dev, hs.dev, nk.dev, (uint32_t)n_tiles, e->d_ctr);
+        else if (wide)
             kmers_tile_kernel<KT, true><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
                                                                     hi.dev, hs.dev, nk.dev, (uint32_t)n_tiles, e->d_ctr);
+        else if (!e->opt.kmers_plain)
+            kmers_tile_kernel<KT, false, true><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
+                                                                           nullptr, hs.dev, nk.dev, (uint32_t)n_tiles, e->d_ctr);
         else
             kmers_tile_kernel<KT, false><<<grid, KT, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical, e->cfg.seed, lo.dev,
                                                                      nullptr, hs.dev, nk.dev, (uint32_t)n_tiles, e->d_ctr);

@@ -259,7 +259,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
 // words cover all its windows, the reverse complement rolls), but nothing is partitioned: every wave
 // transposes its 1024 results through its own 8.5 KiB of LDS so that each store instruction writes 64
 // consecutive positions.  No workgroup barrier anywhere.
-template <int THREADS, bool WIDE>
+template <int THREADS, bool WIDE, bool NT = false>
 __global__ void __launch_bounds__(THREADS)
 kmers_tile_kernel(StreamView s, int k, int canonical, uint64_t seed, uint64_t *__restrict__ out_lo,
                   uint64_t *__restrict__ out_hi, uint64_t *__restrict__ out_hash, uint64_t *__restrict__ out_not,
@@ -343,7 +343,10 @@ kmers_tile_kernel(StreamView s, int k, int canonical, uint64_t seed, uint64_t *_
                 const int e = i * 64 + lane;
                 const uint64_t v = X[(e / PER_THREAD) * PITCH + (e % PER_THREAD)];
                 const uint64_t p = wave0 + (uint64_t)e;
-                if (p < s.n_bases) dst[p] = v;
+                if (p < s.n_bases) {
+                    if constexpr (NT) __builtin_nontemporal_store(v, &dst[p]);       // (streamed out, never read back here)
+                    else dst[p] = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         };

@@ -17,10 +17,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--reads", type=int, default=12_800_000)
+ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE")
 args, _ = ap.parse_known_args()
 gcfg = dk.synth_config(genome_len=64 << 20)
 for k in (31, 51):
     with dk.Engine(k=k, seed=20260313) as eng:
+        for ov in args.opt:
+            name, _, val = ov.partition("=")
+            eng.set_option(name, int(val))
         b = dk.ReadBatch.synth(eng, gcfg, 2, 0, args.reads)
         n = b.stats()["n_bases"]
         lo = torch.zeros(n, dtype=torch.int64, device="cuda:0")
