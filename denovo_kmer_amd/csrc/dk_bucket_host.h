@@ -512,10 +512,14 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
                 list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
     } while (0)
     auto launch = [&](uint64_t region_cap) -> hipError_t {
-        if (per_seg >= (e->opt.cnt_big > 0 ? (uint64_t)e->opt.cnt_big : (WIDE ? 3500u : 7000u))) {
+        // Each geometry keeps a unit in registers up to threads x 16 records (k > 32: x 8), and at a given unit size the smaller
+        // geometry wins (more workgroups per CU overlap their phases: 3.8 K-record units of the whole-genome steps 4.66 ms per step
+        // with 256 threads, 6.74 with 512, 11.6 with 1024), so k <= 32 takes each geometry up to the mean that still leaves 3 sigma
+        // below its capacity
+        if (per_seg >= (e->opt.cnt_big > 0 ? (uint64_t)e->opt.cnt_big : (WIDE ? 3500u : 7900u))) {
             // big segments: 1024 threads hold 8K (k > 32) / 16K records in registers, 256-Kbit bitmaps
             DK_COUNT_LAUNCH(1024, 2048, 8192, 2);
-        } else if (per_seg >= (WIDE ? 1300u : (uint64_t)(e->opt.cnt_mid > 0 ? e->opt.cnt_mid : 3600))) {
+        } else if (per_seg >= (WIDE ? 1300u : (uint64_t)(e->opt.cnt_mid > 0 ? e->opt.cnt_mid : 3900))) {
             DK_COUNT_LAUNCH(512, 2048, 2048, 6);
         } else if (per_seg >= (WIDE ? 600u : 1200u)) {
             // 256 threads hold 2K (k > 32) / 4K records: 2^17 segments at configs[1] leave ~1.6 K absent records each

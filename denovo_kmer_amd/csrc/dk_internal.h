@@ -40,8 +40,8 @@ struct dk_options {
     int force_l3 = 0;             // three partition levels from 8 segments on
     int b1_up = 0;                // shift the level-1 / level-2 bit split
     int count_seg = 0;            // KmerCounter: records per counting segment (default 5000)
-    int cnt_mid = 0;              // seg_count: threshold of the 512-thread geometry (default 3600)
-    int cnt_big = 0;              // seg_count: threshold of the 1024-thread geometry (default 7000, k > 32: 3500)
+    int cnt_mid = 0;              // seg_count: threshold of the 512-thread geometry (default 3900)
+    int cnt_big = 0;              // seg_count: threshold of the 1024-thread geometry (default 7900, k > 32: 3500)
     int cnt_split_to = 0;         // absent-list split: records per unit aimed at (default 6000, k > 32: 3000)
     int repart_bits = 0;          // repart: most hash bits one pass may take (default 10; 9 = round 1's limit, for A/B runs)
     int slabs = 0;                // slab-wise level 2 of insert / accumulate: number of slabs (0 = automatic; a power of two)

@@ -656,6 +656,25 @@ def test_every_seg_count_geometry_counts_exactly(rng, n_reads, k):
         assert res.stats["n_distinct"] == st["n_distinct"] and int(cn.max()) >= 2
 
 
+@pytest.mark.parametrize("k", [31, 51])
+@pytest.mark.parametrize("count_seg", [300, 2500, 6000, 12000])
+def test_seg_count_geometries_by_unit_size(k, count_seg):
+    """count_seg sets the records per counting unit of a KmerCounter batch: a few hundred (128 threads), thousands (256 / 512)
+    and 12 K (the 1024-thread kernel, units held in registers up to 16 K records; k > 32: two chunks per unit)"""
+    d = dk()
+    rng = np.random.default_rng(2024)
+    reads = random_reads(rng, 1500, 150, 151)
+    reads = reads + reads[:500]
+    seq, off = orc.concat_reads(reads)
+    km, cn, st = orc.count_reads(k, True, seq, off)
+    with make_engine("bucketed", k=k, filter_log2_bits=22, seed=99) as eng:
+        eng.set_option("count_seg", count_seg)
+        res = d.KmerCounter(eng).count_sequences(reads)
+        assert_family_ran(eng)
+        assert_result_equals(res, km, cn)
+        assert res.stats["n_distinct"] == st["n_distinct"] and int(cn.max()) >= 2
+
+
 def _forced_geometry_trio(options, expect_stages):
     """small related trio through the bucketed family with kernel geometries forced by engine options
     (dk_engine_set_option test hooks), checked against the oracle"""
