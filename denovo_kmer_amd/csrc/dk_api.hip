@@ -739,6 +739,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"accum_min_u", &dk_options::accum_min_u, 0, 10},
         {"mode", &dk_options::mode, 0, 2},
         {"kmers_plain", &dk_options::kmers_plain, 0, 1},
+        {"scan_positions", &dk_options::scan_positions, 0, 1},
         {"merge_undersize", &dk_options::merge_undersize, 0, 10},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
@@ -771,9 +772,28 @@ static dk_status reads_alloc(dk_engine *e, uint64_t n_bases, uint64_t n_reads, u
     const size_t bw = (n_bases + 31) / 32, mw = (n_bases + 63) / 64;
     dk_status s = pool_alloc(e, (bw + 2) * 8, (void **)&r->d_bases);
     if (s == DK_OK) s = pool_alloc(e, (mw + 2) * 8, (void **)&r->d_mask);
+    if (s == DK_OK) s = pool_alloc(e, 256, (void **)&r->d_uniform);
     if (s != DK_OK) { dk_reads_destroy(r); return s; }
     *out = r;
     return DK_OK;
+}
+
+// The batch may consist of reads of one length (n_bases = n_reads * (L + 1)): have the device check it on `stream`, behind the
+// copies that bring the mask.  known = true: the caller built the stream itself (synthetic reads, uniform ASCII reads).
+static hipError_t reads_mark_uniform(dk_reads *r, hipStream_t stream, bool known)
+{
+    r->stride = 0;
+    if (!r->d_uniform || r->n_reads == 0 || r->n_bases % r->n_reads != 0) return hipSuccess;
+    const uint64_t stride = r->n_bases / r->n_reads;
+    if (stride < 2 || stride > 0xFFFFFFFFULL || r->n_reads > 0x7FFFFFFFULL) return hipSuccess;
+    hipError_t h = hipMemsetD32Async((hipDeviceptr_t)r->d_uniform, 1, 1, stream);
+    if (h == hipSuccess && !known) {
+        const uint64_t grid = (r->n_reads + DIRECT_BLOCK - 1) / DIRECT_BLOCK;
+        verify_stride_kernel<<<(unsigned)grid, DIRECT_BLOCK, 0, stream>>>(r->d_mask, r->n_reads, (uint32_t)stride, r->d_uniform);
+        h = hipGetLastError();
+    }
+    if (h == hipSuccess) r->stride = (uint32_t)stride;
+    return h;
 }
 
 static uint64_t windows_of(const uint64_t *offsets, uint64_t n_reads, uint32_t k)
@@ -816,6 +836,11 @@ dk_status dk_reads_from_ascii(dk_engine *e, const uint8_t *seq, const uint64_t *
             pack_ascii_kernel<<<grid, DIRECT_BLOCK, 0, e->stream>>>(d_seq, d_off, n_reads, n_bases, r->d_bases, r->d_mask);
             h = hipGetLastError();
         }
+        if (h == hipSuccess) {
+            bool uniform = true;                               // reads of one length: the scan deals windows, not positions, to its threads
+            for (uint64_t i = 1; i < n_reads && uniform; i++) uniform = offsets[i + 1] - offsets[i] == offsets[1] - offsets[0];
+            if (uniform) h = reads_mark_uniform(r, e->stream, true);
+        }
         if (h == hipSuccess) h = hipStreamSynchronize(e->stream);   // seq/offsets are borrowed only for the call
         pool_free(e, d_seq);
         pool_free(e, d_off);
@@ -844,6 +869,7 @@ dk_status dk_reads_from_packed(dk_engine *e, const uint64_t *bases, const uint64
     if (n_bases) {
         hipError_t h = hipMemcpyAsync(r->d_bases, bases, (n_bases + 31) / 32 * 8, hipMemcpyHostToDevice, e->stream);
         if (h == hipSuccess) h = hipMemcpyAsync(r->d_mask, mask, (n_bases + 63) / 64 * 8, hipMemcpyHostToDevice, e->stream);
+        if (h == hipSuccess) h = reads_mark_uniform(r, e->stream, false);
         if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
         if (h != hipSuccess) {
             dk_reads_destroy(r);
@@ -879,6 +905,7 @@ dk_status dk_reads_from_packed_async(dk_engine *e, const uint64_t *bases, const 
         if (h == hipSuccess) h = hipStreamWaitEvent(e->copy_stream, e->copy_ev, 0);
         if (h == hipSuccess) h = hipMemcpyAsync(r->d_bases, bases, (n_bases + 31) / 32 * 8, hipMemcpyHostToDevice, e->copy_stream);
         if (h == hipSuccess) h = hipMemcpyAsync(r->d_mask, mask, (n_bases + 63) / 64 * 8, hipMemcpyHostToDevice, e->copy_stream);
+        if (h == hipSuccess) h = reads_mark_uniform(r, e->copy_stream, false);
     }
     if (h == hipSuccess) h = hipEventRecord(r->ready, e->copy_stream);
     if (h != hipSuccess) {
@@ -933,6 +960,10 @@ dk_status dk_reads_attach_device(dk_engine *e, const void *d_bases, const void *
     r->n_reads = n_reads;
     r->n_windows = n_windows;
     r->owns = false;
+    if (n_bases && pool_alloc(e, 256, (void **)&r->d_uniform) == DK_OK) {
+        const hipError_t h = reads_mark_uniform(r, e->stream, false);
+        if (h != hipSuccess) { dk_reads_destroy(r); return fail(e, DK_ERR_HIP, "checking the read lengths failed: %s", hipGetErrorString(h)); }
+    }
     *out = r;
     return DK_OK;
 }
@@ -972,6 +1003,7 @@ dk_status dk_reads_synth(dk_engine *e, const dk_synth_config *cfg, int32_t sampl
         if (grid > 0x7FFFFFFFULL) { dk_reads_destroy(r); return fail(e, DK_ERR_INVALID_ARG, "synthetic batch too large"); }
         synth_kernel<<<(int)grid, DIRECT_BLOCK, 0, e->stream>>>(p, n_bases, r->d_bases, r->d_mask);
         hipError_t h = hipGetLastError();
+        if (h == hipSuccess) h = reads_mark_uniform(r, e->stream, true);
         if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
         if (h != hipSuccess) {
             dk_reads_destroy(r);
@@ -1107,6 +1139,7 @@ void dk_reads_destroy(dk_reads *r)
         pool_free(r->e, r->d_bases);
         pool_free(r->e, r->d_mask);
     }
+    pool_free(r->e, r->d_uniform);
     delete r;
 }
 

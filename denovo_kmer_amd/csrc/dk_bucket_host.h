@@ -320,10 +320,18 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     sv.n_bwords = (r->n_bases + 31) / 32;
     sv.n_mwords = (r->n_bases + 63) / 64;
     const uint32_t n_tiles = (uint32_t)((r->n_bases + p.tile - 1) / p.tile);
+    // window-major thread mapping for batches of one read length (k <= 32; the kernel looks at the batch's verified flag)
+    WindowMajor wmv{0, 0, 0, 0, nullptr};
+    if (!WIDE && !e->opt.scan_positions && r->stride > e->cfg.k && r->d_uniform) {
+        const uint32_t W = r->stride - e->cfg.k;                         // windows per read: L - k + 1 = stride - k
+        const uint32_t tpr = (W + 15) / 16, wpt = (W + tpr - 1) / tpr;
+        if ((uint64_t)r->n_reads * tpr < 0x7FFFFFFFULL) wmv = WindowMajor{r->stride, tpr, wpt, (uint32_t)(r->n_reads * tpr), r->d_uniform};
+    }
 #define DK_SCAN_LAUNCH(TH, PT, W, WIN)                                                                                    \
     scan_part_kernel<TH, PT, W, WIDE, WIN><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical,           \
                                                                       e->cfg.seed, p.b1, p.capw, B.a, B.cnt1, n_tiles,    \
-                                                                      ovf, e->d_ctr, wbits, widx, l1_skew)
+                                                                      ovf, e->d_ctr, wbits, widx, l1_skew,                \
+                                                                      (PT == 16 ? wmv : WindowMajor{0, 0, 0, 0, nullptr}))
     // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
 #define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \
     do {                                                                                                  \

@@ -17,11 +17,27 @@ namespace dk {
 // store latency of one hides behind the hashing of the other inside every wave.
 // WINDOWED: only the k-mers whose hash starts with the wbits (>= 1) bits of widx become records (a hash-range pass of
 // dk_accum_add); the bins are then taken from the b1 bits after the window's.
+// Window-major thread mapping (k <= 32, batches whose reads all have one length L: a flag at every position that is L modulo
+// L + 1, verified on the device when the batch was made -- `ok`).  A read of L bases has L - k + 1 windows but L + 1 stream
+// positions: position by position, 16 per thread, 21 % of the slots of a 150-bp read at k = 31 hash a window that cannot
+// exist (the last k - 1 positions of a read and its separator).  Here a read is dealt to `tpr` threads of `wpt` <= 16
+// consecutive windows each (150 bp, k = 31: 8 threads x 15 windows), so every slot but the rounding holds a real window.
+// The parts cover the offsets 0 .. min(tpr * wpt, L + 1) of their read; whatever starts at an offset in [L - k + 1, L] covers
+// the flagged position L, so no valid window is missed and none is taken twice -- whatever the flags at the positions
+// = L mod L + 1 stand for (a separator, or an N).
+struct WindowMajor {
+    uint32_t stride;               // L + 1; 0 = position-major (the general mapping)
+    uint32_t tpr, wpt;
+    uint32_t n_slots;              // n_reads * tpr (< 2^31)
+    const uint32_t *ok;            // device flag: 1 = every position = L mod stride is flagged
+};
+
 template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE, bool WINDOWED>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
                  typename RecOf<WIDE>::type *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles,
-                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx, uint32_t bin_skew)
+                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx, uint32_t bin_skew,
+                 WindowMajor wmv)
 {
     using R = typename RecOf<WIDE>::type;
     constexpr int TILE = THREADS * PER_THREAD;
@@ -44,12 +60,31 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     Stamps st;
 
     const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
+    // window-major (k <= 32 only; decided once per launch from the batch's device flag): tiles count thread slots, not positions
+    const bool wm = !WIDE && wmv.stride != 0 && *wmv.ok != 0;
+    if (wm) n_tiles = (wmv.n_slots + THREADS - 1) / THREADS;
+    const uint32_t n_win = wm ? wmv.wpt : (uint32_t)PER_THREAD;          // windows a thread hashes per tile
+    // first position of the thread's stretch in `tile`; *lim (if given) = how many of its windows are the thread's own
+    auto pos_of = [&](uint32_t tile, uint32_t *lim = nullptr) -> uint64_t {
+        if (wm) {
+            const uint32_t g = tile * (uint32_t)THREADS + (uint32_t)tid;
+            if (g >= wmv.n_slots) return s.n_bases;                       // beyond the last read: nothing valid
+            const uint32_t r = g / wmv.tpr, off = (g - r * wmv.tpr) * wmv.wpt;
+            // the read's last part stops at the read's own positions: what starts beyond belongs to the next read's first part
+            if (lim) *lim = wmv.stride - off < wmv.wpt ? wmv.stride - off : wmv.wpt;
+            return (uint64_t)r * wmv.stride + off;
+        }
+        return (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
+    };
+    // (k <= 32: the third bases word is needed only where a thread's stretch starts deep inside a word, i.e. window-major;
+    // its top half is enough -- 16 windows + k - 1 bases end at most 93 bits after the stretch's first bit)
     auto load_words = [&](uint32_t tile, uint64_t &w0, uint64_t &w1, uint64_t &w2, uint64_t &m0, uint64_t &m1) {
-        const uint64_t p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
+        const uint64_t p0 = pos_of(tile);
         const uint64_t bw = p0 >> 5, mw = p0 >> 6;
         w0 = s.bases[bw < last_b ? bw : last_b];
         w1 = s.bases[bw + 1 < last_b ? bw + 1 : last_b];
-        w2 = WIDE ? s.bases[bw + 2 < last_b ? bw + 2 : last_b] : 0;
+        if constexpr (WIDE) w2 = s.bases[bw + 2 < last_b ? bw + 2 : last_b];
+        else w2 = wm ? (uint64_t)((const uint32_t *)s.bases)[2 * (bw + 2 < last_b ? bw + 2 : last_b) + 1] : 0;   // the word's top half
         m0 = s.mask[mw < last_m ? mw : last_m];
         m1 = s.mask[mw + 1 < last_m ? mw + 1 : last_m];
     };
@@ -64,10 +99,12 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     uint64_t p0 = 0, v0 = 0, v1 = 0, v2 = 0, mh = 0, ml = 0, rch = 0, rcl = 0;
     uint32_t okbits = 0;                                   // k <= 32: bit (PER_THREAD - 1 - j) = window j is a k-mer
     auto prep = [&](uint32_t tile, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t m0, uint64_t m1) {
-        p0 = (uint64_t)tile * TILE + (uint64_t)tid * PER_THREAD;
-        const int o = 2 * (int)(p0 & 31);                 // PER_THREAD 8: 0,16,32,48; 16: 0,32
+        uint32_t lim = n_win;
+        p0 = pos_of(tile, &lim);
+        const int o = 2 * (int)(p0 & 31);                 // position-major: PER_THREAD 8: 0,16,32,48; 16: 0,32; window-major: any
         v0 = o ? (w0 << o) | (w1 >> (64 - o)) : w0;
-        v1 = o ? (w1 << o) | (WIDE ? w2 >> (64 - o) : 0) : w1;
+        // (k <= 32: w2 holds the TOP half of the third word in its low 32 bits)
+        v1 = o ? (w1 << o) | ((WIDE ? w2 : w2 << 32) >> (64 - o)) : w1;
         v2 = WIDE ? (o ? w2 << o : w2) : 0;
         const int ms = (int)(p0 & 63);
         mh = ms ? (m0 << ms) | (m1 >> (64 - ms)) : m0;
@@ -84,6 +121,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             const uint32_t inside = left >= (uint64_t)PER_THREAD ? (1u << PER_THREAD) - 1u
                                                                  : ~((1u << (PER_THREAD - (uint32_t)left)) - 1u) & ((1u << PER_THREAD) - 1u);
             okbits = ~bad & inside;
+            if (wm) okbits &= ~((1u << (PER_THREAD - lim)) - 1u);          // the thread's part of its read: lim <= n_win windows
             if constexpr (WINDOWED) n_all += (uint32_t)__popc(okbits);
         }
     };
@@ -148,7 +186,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
 #pragma unroll
         for (int j = 0; j < PER_THREAD; j++) {
             uint32_t r = 0;
-            if (window(j, hs[j])) {
+            if ((uint32_t)j < n_win && window(j, hs[j])) {
                 valid |= 1u << j;
                 r = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
             }
@@ -218,7 +256,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                 }
                 if (has_next) {
                     uint32_t r = 0;
-                    if (window(j, hs[j])) {
+                    if ((uint32_t)j < n_win && window(j, hs[j])) {
                         valid |= 1u << j;
                         r = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
                     }

@@ -48,6 +48,7 @@ struct dk_options {
     int slab_mb = 0;              // automatic slabs: room for one slab's regions in MiB (default 12288)
     int ovf_cap = 0;              // capacity of the partition's overflow list in records (test hook; 0 = an eighth of the batch)
     int accum_min_u = 0;          // dk_accum_create: at least 2^n counting units per segment (test hook: packed units on small sets)
+    int scan_positions = 0;       // scan_part: 1 = always position-major, never window-major (A/B runs, tests)
     int kmers_plain = 0;          // dk_reads_kmers: 1 = ordinary stores for the outputs instead of non-temporal ones (A/B)
     int mode = 0;                 // kernel family override: 0 = dk_config.mode, 1 = direct, 2 = bucketed
     int l2_packed = 0;            // 1 = level-2 regions of >= 16 prefix bits hold packed 6-byte records (slower: DESIGN.md section 9; A/B runs, tests)
@@ -98,6 +99,10 @@ struct dk_reads {
     uint64_t n_bases, n_reads, n_windows;
     bool owns;
     hipEvent_t ready = nullptr;   // dk_reads_from_packed_async: the upload's completion on the copy stream
+    // Uniform read length (window-major scan, dk_bucket_scan.h): stride = L + 1 when the batch may consist of reads of one
+    // length L (0 = no); *d_uniform (device) = 1 once a kernel has verified that every position = L mod stride is flagged
+    uint32_t stride = 0;
+    uint32_t *d_uniform = nullptr;
 };
 
 struct dk_set {

@@ -94,6 +94,17 @@ pack_ascii_kernel(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ 
     if (p0 + 32 < n_bases) bases[2 * chunk + 1] = b1;
 }
 
+// flag <- 0 unless every position that is stride - 1 modulo stride is flagged in the mask (separator, or N): what the
+// window-major scan relies on (dk_bucket_scan.h); one thread per read
+__global__ void __launch_bounds__(DIRECT_BLOCK)
+verify_stride_kernel(const uint64_t *__restrict__ mask, uint64_t n_reads, uint32_t stride, uint32_t *flag)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t p = r * stride + (stride - 1);
+    if (!((mask[p >> 6] >> (63 - (p & 63))) & 1ULL)) *flag = 0;
+}
+
 // ---- synthetic trio reads, generated straight into the packed format ----
 struct SynthParams {
     uint64_t seed, genome_len, span;   // span = genome_len - read_len + 1

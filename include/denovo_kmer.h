@@ -139,7 +139,9 @@ dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
  *   even where 6-byte packed ones apply), "accum_min_u" 0..10 (at least 2^n counting units per segment),
  *   "mode" 0..2 (kernel family override: 0 = dk_config.mode, 1 = direct, 2 = bucketed), "l2_packed" 0..1 (6-byte records in
  *   the level-2 regions too: measured slower, kept for A/B runs), "merge_undersize" 0..10 (dk_result_merge starts with pass
- *   tables 2^n times too small: its redo path) */
+ *   tables 2^n times too small: its redo path), "repart_pieces" 0..2 (level 2 reads a bin piece by piece / as the concatenation
+ *   of its pieces; 0 = automatic), "scan_positions" 0..1 (1: the scan never deals windows instead of positions to its threads
+ *   for batches of one read length), "kmers_plain" 0..1 (1: ordinary instead of non-temporal stores in dk_reads_kmers) */
 dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
 /* What the engine did / holds, by name: "plan_levels", "plan_b1", "plan_b2", "plan_b3", "plan_sbits", "plan_slabs",
  * "plan_scan_variant", "plan_segment_bits" (the partition plan of the last bucketed operation), "pool_bytes_in_use",

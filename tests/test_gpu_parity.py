@@ -922,3 +922,68 @@ def test_sunk_unit_running_full_falls_back_to_the_plain_probe(rng):
         assert_result_equals(res, km, cn)
         assert_stats(res.stats, pst, ["n_windows", "n_valid", "n_absent", "n_distinct"])
         assert int(cn.max()) >= 4000
+
+
+# ---- window-major scan: batches whose reads all have one length ---------------------------------------------
+
+@pytest.mark.parametrize("k", [1, 5, 16, 21, 31, 32])
+@pytest.mark.parametrize("read_len", [32, 47, 150, 151, 1000])
+def test_uniform_read_lengths_take_the_window_major_scan_and_agree(k, read_len):
+    """reads of ONE length are dealt to the scan's threads by windows, not by positions (dk_bucket_scan.h: WindowMajor);
+    every k / read-length pairing -- parts that end exactly at the read's last window, parts that would run into the
+    next read (k = 1), more threads per read than k (1000-bp reads) -- must count what the oracle counts, with the option
+    off (position-major) and on, through ASCII input, packed upload and an attached device buffer"""
+    d = dk()
+    if read_len < k:
+        pytest.skip("no windows")
+    rng = np.random.default_rng(1000 * k + read_len)
+    reads = random_reads(rng, max(40, 40000 // read_len), read_len, read_len, n_rate=0.004)
+    reads = reads + reads[:7]
+    seq, off = orc.concat_reads(reads)
+    km, cn, st = orc.count_reads(k, True, seq, off)
+    bases, mask, n_bases = orc.pack_reads(seq, off)
+    for positions in (0, 1):
+        with make_engine("bucketed", k=k, filter_log2_bits=22, seed=99) as eng:
+            eng.set_option("scan_positions", positions)
+            batches = [d.ReadBatch.from_sequences(eng, reads),
+                       d.ReadBatch.from_packed(eng, bases, mask, n_bases, len(reads), orc.n_windows(off, k))]
+            for b in batches:
+                res = d.KmerCounter(eng).count_reads(b)
+                assert_family_ran(eng)
+                assert_result_equals(res, km, cn)
+                assert res.stats["n_valid"] == st["n_valid"]
+                res.close()
+
+
+def test_streams_that_only_look_uniform_are_counted_exactly():
+    """n_bases divides by n_reads but the reads differ in length: the device check clears the batch's flag and the scan
+    stays position-major; and a stream whose flags at the positions = L mod L + 1 are all set although the reads are NOT
+    of one length (an N sits where a separator would be, the real separators are elsewhere) may take the window-major
+    mapping -- it depends on the flags only -- and still counts exactly"""
+    d = dk()
+    rng = np.random.default_rng(77)
+    k = 21
+    # (a) 60 reads of 100 and 60 of 200 bases: (100 + 1) * 60 + (200 + 1) * 60 = 120 * 151
+    a = random_reads(rng, 60, 100, 100) + random_reads(rng, 60, 200, 200)
+    rng.shuffle(a)
+    # (b) as if 150-bp reads: position 150 of every 151 flagged -- by a separator or by an N inside a longer read
+    stretch = "".join(np.array(list("ACGT"))[rng.integers(0, 4, size=151 * 40 - 1)])
+    chars = list(stretch)
+    for p in range(150, len(chars), 151):
+        chars[p] = "N"
+    b = ["".join(chars[:151 * 10 - 1]), "".join(chars[151 * 10:151 * 25 - 1]), "".join(chars[151 * 25:])]
+    for reads in (a, b):
+        seq, off = orc.concat_reads(reads)
+        n_pos = int(off[-1]) + len(reads)
+        km, cn, st = orc.count_reads(k, True, seq, off)
+        bases, mask, n_bases = orc.pack_reads(seq, off)
+        assert n_bases == n_pos
+        with make_engine("bucketed", k=k, filter_log2_bits=22, seed=5) as eng:
+            # (b): 3 reads, but a host that says 40 reads makes n_bases / n_reads = 151: the flags allow it
+            n_say = len(reads) if reads is a else 40
+            assert n_bases % n_say == 0
+            batch = d.ReadBatch.from_packed(eng, bases, mask, n_bases, n_say, orc.n_windows(off, k))
+            res = d.KmerCounter(eng).count_reads(batch)
+            assert_result_equals(res, km, cn)
+            assert res.stats["n_valid"] == st["n_valid"]
+            res.close()
