@@ -512,11 +512,14 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
 #define DK_COUNT_LAUNCH(TH, SLOTS, BM, PER_CU)                                                                                  \
     do {                                                                                                                        \
         const unsigned cgrid = (unsigned)std::min<uint64_t>(n_units, (uint64_t)e->n_cu * PER_CU);                               \
+        /* (k <= 32 has the LDS for bitmaps of twice the words below the 1024-thread geometry: >= 16 bits per record up to the */ \
+        /* geometry's capacity -- 6 % instead of 11 % of the unique records take the table path) */                               \
+        constexpr int BMW = (WIDE || TH >= 1024) ? BM : 2 * BM;                                                                  \
         if (packed && !WIDE)                                                                                                    \
-            seg_count_kernel<TH, SLOTS, BM, WIDE, !WIDE><<<cgrid, TH, 0, e->stream>>>(                                          \
+            seg_count_kernel<TH, SLOTS, BMW, WIDE, !WIDE><<<cgrid, TH, 0, e->stream>>>(                                         \
                 list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
         else                                                                                                                    \
-            seg_count_kernel<TH, SLOTS, BM, WIDE, false><<<cgrid, TH, 0, e->stream>>>(                                          \
+            seg_count_kernel<TH, SLOTS, BMW, WIDE, false><<<cgrid, TH, 0, e->stream>>>(                                         \
                 list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
     } while (0)
     auto launch = [&](uint64_t region_cap) -> hipError_t {
