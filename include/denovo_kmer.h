@@ -298,7 +298,9 @@ dk_status dk_accum_stats(const dk_accum *a, dk_stats *out);     /* totals so far
  * exchange unit ranges so that rank r holds units [r * n_units / P, (r + 1) * n_units / P) of every rank and counts
  * them -- the result stays sharded by hash range (the ranks' tables are disjoint; their union is the whole answer),
  * so counts and min_count are exact across the read shards and no rank ever holds the whole table.
- *   dk_accum_geometry      units of the window, records per unit, bytes per record
+ *   dk_accum_geometry      units of the window, records per unit, bytes per record: 16 (k > 32), 8, or 6 -- packed units, where all
+ *                          records of a unit share at least 16 leading hash bits: a unit is a row of 384-byte blocks of 64 records,
+ *                          64 x u32 (hash bits 0..31) then 64 x u16 (bits 32..47); the unit index supplies the bits above
  *   dk_accum_device_view   the store (n_units * unit_cap records, unit-major), the fills (n_units u32, records held by
  *                          each unit; values above unit_cap mean unit_cap) and the overflow list; synchronises
  *   dk_accum_finish_pieces counts units [first_unit, first_unit + n_units) from n_pieces (<= 8) slices laid out piece
