@@ -346,9 +346,13 @@ def main():
         # the library's for the set and the accumulator) bring their own channel buffers
         reserved = max(0, free - ((5 if world == 1 else 20) << 30))
         t0 = time.perf_counter()
-        eng.reserve(reserved)
-        reserve_s = time.perf_counter() - t0
-        progress("arena of %.1f GB reserved in %.2f s" % (reserved / 1e9, reserve_s))
+        try:
+            eng.reserve(reserved)
+            reserve_s = time.perf_counter() - t0
+            progress("arena of %.1f GB reserved in %.2f s" % (reserved / 1e9, reserve_s))
+        except dk.DkError as exc:                            # one block of that size was refused: the grow-only pool takes over
+            progress("arena of %.1f GB refused (%s): allocating as needed" % (reserved / 1e9, exc))
+            reserved = 0
 
     def free_bytes():
         if reserved:
