@@ -115,7 +115,7 @@ def test_two_ranks_exact_set_union_matches_whole_input_oracle(mode, k):
         assert np.array_equal(mhi, km["hi"]) and np.array_equal(mlo, km["lo"]) and np.array_equal(mcnt, cn)
 
 
-def _accum_worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, cap, q):
+def _accum_worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, cap, q, opts=()):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -129,6 +129,8 @@ def _accum_worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, cap,
         torch.cuda.set_device(0)
         gcfg = dk.synth_config(genome_len=100_000)
         eng = dk.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=nh, seed=seed, device_id=0, mode=mode, rank=rank, world_size=world)
+        for name, val in opts:
+            eng.set_option(name, val)
         filt = torch.zeros((1 << log2_bits) // 64, dtype=torch.int64, device="cuda:0")
         torch.cuda.synchronize()
         ks = dk.KmerSet(eng, device_ptr=filt.data_ptr(), keepalive=filt)
@@ -137,6 +139,10 @@ def _accum_worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, cap,
             ks.insert_reads(dk.ReadBatch.synth(eng, gcfg, s, lo, hi - lo))
         or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=True)
         out = {}
+        if opts:
+            probe = dk.ChildAccumulator(eng, ks, capacity_records=cap)
+            assert probe.geometry()[2] == (6 if dict(opts).get("accum_min_u", 0) >= 8 and k <= 32 else 16 if k > 32 else 8)
+            probe.close()
         for windows in (1, 2):
             acc = dk.ChildAccumulator(eng, ks, capacity_records=cap, window_count=windows)
             for mc in (1, 2):
@@ -158,19 +164,22 @@ def _accum_worker(rank, world, port, n_reads, k, log2_bits, nh, seed, mode, cap,
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("mode,k,cap", [("bucketed", 31, 400_000), ("direct", 45, 400_000), ("bucketed", 31, 1)])
-def test_two_ranks_exchange_accumulators_for_exact_counts_across_shards(mode, k, cap):
+@pytest.mark.parametrize("mode,k,cap,log2_bits,opts", [("bucketed", 31, 400_000, 24, ()), ("direct", 45, 400_000, 24, ()), ("bucketed", 31, 1, 24, ()),
+                                                       ("bucketed", 31, 400_000, 27, (("accum_min_u", 8),)),
+                                                       ("direct", 31, 1, 27, (("accum_min_u", 8),))])
+def test_two_ranks_exchange_accumulators_for_exact_counts_across_shards(mode, k, cap, log2_bits, opts):
     """every rank accumulates its child shard; the ranks swap unit ranges and count their own share of the hash space
     from both ranks' pieces: the union of the ranks' tables must be the oracle's table of the WHOLE child, counts and
-    min_count included (cap = 1: nearly everything travels through the all-gathered overflow lists)"""
-    n_reads, log2_bits, nh, seed, world = 6000, 24, 4, 31337, 2
+    min_count included (cap = 1: nearly everything travels through the all-gathered overflow lists; accum_min_u = 8 on a
+    2^27-bit set: packed 6-byte units, counted from TWO piece-major pieces -- what a native exchange between GPUs delivers)"""
+    n_reads, nh, seed, world = 6000, 4, 31337, 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, n_reads, k, log2_bits, nh, seed, mode, cap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_accum_worker, args=(r, world, port, n_reads, k, log2_bits, nh, seed, mode, cap, q, opts)) for r in range(world)]
     for p in procs:
         p.start()
     outs = dict(q.get(timeout=500) for _ in range(world))
