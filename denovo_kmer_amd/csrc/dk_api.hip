@@ -741,6 +741,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"kmers_plain", &dk_options::kmers_plain, 0, 1},
         {"scan_positions", &dk_options::scan_positions, 0, 1},
         {"merge_undersize", &dk_options::merge_undersize, 0, 10},
+        {"comm_staging_kb", &dk_options::comm_staging_kb, 0, 1 << 30},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},
@@ -1538,7 +1539,7 @@ dk_status dk_comm_init(dk_engine *e, const uint8_t *id, uint32_t rank, uint32_t 
         memcpy(&u, id, sizeof u);
         const int r = api->CommInitRank(&c->comm, (int)world_size, u, (int)rank);
         if (r != RCCL_SUCCESS) { delete c; return fail(e, DK_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(r)); }
-        c->staging_bytes = 1ULL << 30;
+        c->staging_bytes = e->opt.comm_staging_kb ? (uint64_t)e->opt.comm_staging_kb << 10 : 1ULL << 30;
         const dk_status st = pool_alloc(e, c->staging_bytes, &c->staging);
         if (st != DK_OK) { (void)api->CommDestroy(c->comm); delete c; return st; }
     }

@@ -47,10 +47,17 @@ inline RcclApi *rccl()
     static bool tried = false;
     if (tried) return &api;
     tried = true;
+    // DK_RCCL_LIBRARY names the library outright (a non-standard install; the tests point it at tests/rccl_shim, which
+    // runs several ranks on one GPU).  A named library that does not load is an error, not a reason to fall back.
+    const char *named = getenv("DK_RCCL_LIBRARY");
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (api.lib) break;
+    if (named && *named) {
+        api.lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char *n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
     }
     if (!api.lib) { api.err = std::string("cannot load librccl: ") + dlerror(); return &api; }
     struct { const char *name; void **slot; } syms[] = {

@@ -141,7 +141,8 @@ dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
  *   the level-2 regions too: measured slower, kept for A/B runs), "merge_undersize" 0..10 (dk_result_merge starts with pass
  *   tables 2^n times too small: its redo path), "repart_pieces" 0..2 (level 2 reads a bin piece by piece / as the concatenation
  *   of its pieces; 0 = automatic), "scan_positions" 0..1 (1: the scan never deals windows instead of positions to its threads
- *   for batches of one read length), "kmers_plain" 0..1 (1: ordinary instead of non-temporal stores in dk_reads_kmers) */
+ *   for batches of one read length), "kmers_plain" 0..1 (1: ordinary instead of non-temporal stores in dk_reads_kmers),
+ *   "comm_staging_kb" (size of the staging buffer dk_comm_init takes, KiB; 0 = 1 GiB; at least 64 KiB per peer) */
 dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
 /* What the engine did / holds, by name: "plan_levels", "plan_b1", "plan_b2", "plan_b3", "plan_sbits", "plan_slabs",
  * "plan_scan_variant", "plan_segment_bits" (the partition plan of the last bucketed operation), "pool_bytes_in_use",
@@ -229,7 +230,8 @@ void      dk_set_destroy(dk_set *s);
  * then combines the ranks' sets in place -- bitwise OR for a Bloom filter, key union for DK_SET_EXACT -- after which
  * every rank holds the whole parent set and probes its child shard locally.  RCCL has no OR reduction, so the
  * library composes it on the engine's stream: all-to-all of slices (ncclSend/ncclRecv) -> local OR / union kernel ->
- * ncclAllGather, in pieces that bound the staging memory (1 GiB).  librccl.so.1 is loaded on first use.
+ * ncclAllGather, in pieces that bound the staging memory (1 GiB).  librccl.so.1 is loaded on first use; the environment
+ * variable DK_RCCL_LIBRARY names another file to load instead (no fallback if it does not load).
  *   dk_comm_unique_id  one rank creates the id; the host hands the 128 bytes to the other ranks (MPI, TCP, a file)
  *   dk_comm_init       collective over all ranks: joins the engine to the communicator (one per engine).  world_size 1
  *                      with id NULL needs no RCCL at all; world_size 1 WITH an id makes a real communicator of one rank

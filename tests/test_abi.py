@@ -159,3 +159,22 @@ def test_exchange_layout_arithmetic_for_two_to_eight_ranks():
                 # the pieces tile the slice: ceil(sl / p) groups, the last one shorter
                 assert sum(min(p, sl - off) for off in range(0, sl, p)) == sl
     assert lib.dk_comm_layout(1 << 20, 1 << 20, 3, 2, 4, C.byref(piece), slots) != 0     # rank outside the world
+
+
+def test_a_named_rccl_library_that_does_not_load_is_an_error_not_a_fallback():
+    """DK_RCCL_LIBRARY replaces the search for librccl (the multi-rank GPU tests point it at tests/rccl_shim): a wrong path
+    must surface as DK_ERR_UNSUPPORTED from dk_comm_unique_id rather than silently picking the system's library"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import denovo_kmer_amd as d\n"
+            "try:\n"
+            "    d.Engine.comm_unique_id()\n"
+            "except d.DkError as exc:\n"
+            "    print('refused:', exc)\n"
+            "else:\n"
+            "    print('loaded')\n" % ROOT)
+    env = dict(os.environ, DK_RCCL_LIBRARY="/nonexistent/librccl_shim.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "refused:" in out.stdout and "cannot load librccl" in out.stdout

@@ -351,3 +351,156 @@ def test_native_accumulator_exchange_with_one_rank_as_its_own_peer(k, min_u, pla
         eng.comm_finalize()
         acc.close()
         ks.close()
+
+
+# ---- the native collectives with MORE than one rank, on one GPU, over tests/rccl_shim ------------------------------------
+def _shim_path():
+    """build tests/rccl_shim/shim.cpp (a shared-memory stand-in for librccl, test infrastructure only) on first use"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "rccl_shim", "shim.cpp")
+    out_dir = os.path.join(ROOT, "tests", "rccl_shim", "_build")
+    out = os.path.join(out_dir, "librccl_shim.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                               "-o", out, src, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def _native_worker(rank, world, shim, idq, n_reads, k, log2_bits, set_kind, staging_kb, cap, opts, q):
+    os.environ["DK_RCCL_LIBRARY"] = shim
+    sys.path.insert(0, ROOT)
+    import denovo_kmer_amd as dk
+    from denovo_kmer_amd.dist import shard_range
+    gcfg = dk.synth_config(genome_len=100_000)
+    eng = dk.Engine(k=k, filter_log2_bits=log2_bits, n_hashes=4, seed=31337, device_id=0, mode="bucketed",
+                    rank=rank, world_size=world, set_kind=set_kind)
+    eng.set_option("comm_staging_kb", staging_kb)
+    for name, val in opts:
+        eng.set_option(name, val)
+    if rank == 0:
+        uid = eng.comm_unique_id()
+        for _ in range(world - 1):
+            idq.put(uid)
+    else:
+        uid = idq.get(timeout=300)
+    ks = dk.KmerSet(eng)
+    lo, hi = shard_range(n_reads, rank, world)
+    for s in (0, 1):
+        ks.insert_reads(dk.ReadBatch.synth(eng, gcfg, s, lo, hi - lo))
+    eng.comm_init(uid, rank, world)
+    sent = ks.allreduce_or()
+    table = ks.to_host().copy()
+    out = {"table": table, "sent": sent, "n_keys": ks.popcount()}
+    child = dk.ReadBatch.synth(eng, gcfg, 2, lo, hi - lo)
+    res = dk.KmerCounter(eng).child_only(child, ks)
+    out["local"] = res.to_host()
+    res.close()
+    if set_kind == "bloom":
+        for mc in (1, 2):
+            acc = dk.ChildAccumulator(eng, ks, capacity_records=cap)
+            half = (hi - lo) // 2
+            acc.add(dk.ReadBatch.synth(eng, gcfg, 2, lo, half))
+            acc.add(dk.ReadBatch.synth(eng, gcfg, 2, lo + half, hi - lo - half))
+            out[("geometry", mc)] = acc.geometry()
+            got = acc.exchange_finish(min_count=mc)
+            out[("accum", mc)] = got.to_host(sort=False)
+            out[("accum_sent", mc)] = got.bytes_sent
+            got.close()
+            acc.close()
+    q.put((rank, out))
+    eng.comm_finalize()
+    ks.close()
+    eng.close()
+
+
+def _run_native(world, n_reads, k, log2_bits, set_kind, staging_kb, cap, opts=()):
+    shim = _shim_path()
+    ctx = mp.get_context("spawn")
+    q, idq = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, shim, idq, n_reads, k, log2_bits, set_kind, staging_kb, cap, opts, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        outs = dict(q.get(timeout=500) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    return outs
+
+
+def _sum_tables(parts):
+    """per-rank (hi, lo, count) lists of the ranks' own child shards -> one table with the counts summed per k-mer"""
+    hi = np.concatenate([p[0] for p in parts])
+    lo = np.concatenate([p[1] for p in parts])
+    cnt = np.concatenate([p[2] for p in parts]).astype(np.uint64)
+    order = np.lexsort((lo, hi))
+    hi, lo, cnt = hi[order], lo[order], cnt[order]
+    first = np.ones(len(lo), dtype=bool)
+    first[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+    return hi[first], lo[first], np.add.reduceat(cnt, np.flatnonzero(first)) if len(lo) else cnt
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,k,log2_bits,staging_kb,cap,opts", [
+    (2, 31, 26, 0, 400_000, ()),                          # one piece per slice
+    (2, 31, 26, 1024, 400_000, ()),                       # 4-MiB slices through 1 MiB of staging: four pieces
+    (4, 31, 27, 1536, 400_000, (("accum_min_u", 8),)),    # four ranks, three peers of 512 KiB each; packed 6-byte units
+    (4, 45, 26, 640, 1, ()),                              # 16-byte records, nearly everything through the overflow lists
+])
+def test_native_collectives_between_ranks_through_the_c_abi(world, k, log2_bits, staging_kb, cap, opts):
+    """dk_comm_init / dk_set_allreduce_or / dk_accum_exchange_finish with 2 and 4 ranks -- the calls a host without torch
+    makes -- on one GPU: tests/rccl_shim stands in for librccl (which refuses two ranks on a device) and moves every
+    ncclSend / ncclRecv / ncclAllGather through shared memory, so peer indices, staging slots, piece loops and the in-place
+    exchange run as they do between GPUs.  Every rank's set must equal the oracle's filter of the WHOLE parent input, and
+    the union of the ranks' count tables the oracle's table of the WHOLE child.  RCCL itself between GPUs stays the
+    driver's run."""
+    n_reads = 6000
+    outs = _run_native(world, n_reads, k, log2_bits, "bloom", staging_kb, cap, opts)
+    ocfg = orc.synth_cfg(genome_len=100_000)
+    f = orc.new_filter(log2_bits)
+    for smp in (0, 1):
+        seq, off = orc.synth_reads(ocfg, smp, 0, n_reads)
+        orc.bloom_insert(f, log2_bits, 4, 31337, k, True, seq, off)
+    for r in range(world):
+        assert np.array_equal(outs[r]["table"].view(np.uint64), f.view(np.uint64)), "rank %d holds a different set" % r
+        assert outs[r]["sent"] == 2 * (world - 1) * (1 << log2_bits) // 8 // world
+    cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+    km, cn, _ = orc.bloom_probe(f, log2_bits, 4, 31337, k, True, cseq, coff, 1)
+    hi, lo, cnt = _sum_tables([outs[r]["local"] for r in range(world)])
+    assert np.array_equal(hi, km["hi"]) and np.array_equal(lo, km["lo"]) and np.array_equal(cnt, cn.astype(np.uint64))
+    for mc in (1, 2):
+        km, cn, _ = orc.bloom_probe(f, log2_bits, 4, 31337, k, True, cseq, coff, mc)
+        parts = [outs[r][("accum", mc)] for r in range(world)]
+        hi, lo, cnt = (np.concatenate([p[i] for p in parts]) for i in range(3))
+        order = np.lexsort((lo, hi))
+        assert np.array_equal(hi[order], km["hi"]) and np.array_equal(lo[order], km["lo"]) and np.array_equal(cnt[order], cn)
+        assert all(len(p[1]) > 0 for p in parts)             # every rank counted a share of the hash space
+        assert all(outs[r][("accum_sent", mc)] > 0 for r in range(world))
+        want_bytes = 6 if dict(opts).get("accum_min_u", 0) >= 8 and k <= 32 else 16 if k > 32 else 8
+        assert all(outs[r][("geometry", mc)][2] == want_bytes for r in range(world))
+    assert int(cn.max()) >= 2
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,k,staging_kb", [(2, 31, 512), (4, 45, 0)])
+def test_native_union_of_exact_sets_between_ranks(world, k, staging_kb):
+    """the exact set's all-reduce (union_slices_kernel on received table slices) with 2 and 4 ranks over tests/rccl_shim"""
+    n_reads, log2_bits = 4000, 27
+    outs = _run_native(world, n_reads, k, log2_bits, "exact", staging_kb, 0)
+    ocfg = orc.synth_cfg(genome_len=100_000)
+    seqs = [orc.synth_reads(ocfg, s, 0, n_reads) for s in (0, 1)]
+    allseq = np.concatenate([s[0] for s in seqs])
+    alloff = np.concatenate([seqs[0][1], seqs[1][1][1:] + seqs[0][1][-1]])
+    cseq, coff = orc.synth_reads(ocfg, 2, 0, n_reads)
+    km, cn, _ = orc.exact_child_only(k, True, allseq, alloff, cseq, coff)
+    pk, _, _ = orc.count_reads(k, True, allseq, alloff)
+    for r in range(1, world):
+        assert np.array_equal(outs[r]["table"], outs[0]["table"])
+    assert all(outs[r]["n_keys"] == len(pk) for r in range(world))
+    hi, lo, cnt = _sum_tables([outs[r]["local"] for r in range(world)])
+    assert np.array_equal(hi, km["hi"]) and np.array_equal(lo, km["lo"]) and np.array_equal(cnt, cn.astype(np.uint64))
