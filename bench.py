@@ -416,11 +416,14 @@ def main():
     set_hint(batch)
     allreduce_ms, allreduce_bytes, allreduce_path = 0.0, 0, None
     native = False
+    # a library named by DK_RCCL_LIBRARY is NOT librccl (tests/rccl_shim in the one-GPU rehearsal): the labels say so
+    rccl_note = (" [DK_RCCL_LIBRARY=%s stands in for librccl]" % os.path.basename(os.environ["DK_RCCL_LIBRARY"])) if os.environ.get("DK_RCCL_LIBRARY") else ""
     if world > 1:
         # native path: the library's own RCCL communicator (dk_comm_init + dk_set_allreduce_or), as a host without torch
         # would run it; the gloo rehearsal (several ranks on one GPU) and any failure to set it up use the
         # torch.distributed composition of the same three steps
-        if not on_host and not args.single_device:
+        # (DK_RCCL_LIBRARY set in a single-device rehearsal: the library's collectives over tests/rccl_shim, several ranks on one GPU)
+        if (not on_host and not args.single_device) or (args.single_device and os.environ.get("DK_RCCL_LIBRARY")):
             try:
                 comm_init_from_torch(eng)
                 native = True
@@ -434,7 +437,7 @@ def main():
         t0 = time.perf_counter()
         if native:
             allreduce_bytes = kset.allreduce_or()
-            allreduce_path = "dk_set_allreduce_or (RCCL send/recv + HIP OR kernel + ncclAllGather on the engine stream)"
+            allreduce_path = "dk_set_allreduce_or (RCCL send/recv + HIP OR kernel + ncclAllGather on the engine stream)" + rccl_note
         else:
             allreduce_bytes = or_allreduce_(filt, local_reduce_fn(eng), stage_through_cpu=on_host)
             allreduce_path = "torch.distributed all_to_all_single + dk_or_reduce_slices + all_gather_into_tensor" + (" staged through the host (gloo rehearsal)" if on_host else "")
@@ -827,7 +830,7 @@ def main():
         if ingest:
             out["ingest_host"] = ingest
         if world > 1 and wgs:
-            out["config"]["accumulator_exchange"] = ("dk_accum_exchange_finish (RCCL, in place)" if native else "torch.distributed (rehearsal / fallback)")
+            out["config"]["accumulator_exchange"] = ("dk_accum_exchange_finish (RCCL, in place)" + rccl_note if native else "torch.distributed (rehearsal / fallback)")
             out["config"]["accumulator_exchange_bytes_sent_rank0"] = exchange_bytes[0]
         if args.set_kind == "exact":
             out["parent_build"]["exact_set_load"] = popc / (filter_bytes / (16 if k > 32 else 8))

@@ -189,14 +189,17 @@ int ncclRecv(void *buf, size_t count, int type, int peer, Comm *c, hipStream_t s
 int ncclAllGather(const void *send, void *recv, size_t count, int type, Comm *c, hipStream_t stream)
 {
     const size_t nb = count * type_bytes(type);
-    if (nb > MAILBOX) return 5;
     if (hipStreamSynchronize(stream) != hipSuccess) return 1;
-    if (hipMemcpy(box(c, c->rank, c->rank), send, nb, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-    barrier(c);
     int rc = 0;
-    for (int q = 0; q < c->n; q++)
-        if (hipMemcpy((char *)recv + (size_t)q * nb, box(c, q, q), nb, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
-    barrier(c);
+    for (size_t off = 0; off < nb || (nb == 0 && off == 0); off += MAILBOX) {        // contributions larger than a mailbox go in chunks
+        const size_t n = nb - off < MAILBOX ? nb - off : MAILBOX;
+        if (n && hipMemcpy(box(c, c->rank, c->rank), (const char *)send + off, n, hipMemcpyDeviceToHost) != hipSuccess) rc = 1;
+        barrier(c);
+        for (int q = 0; q < c->n && n; q++)
+            if (hipMemcpy((char *)recv + (size_t)q * nb + off, box(c, q, q), n, hipMemcpyHostToDevice) != hipSuccess) rc = 1;
+        barrier(c);
+        if (nb == 0) break;
+    }
     return rc;
 }
 
