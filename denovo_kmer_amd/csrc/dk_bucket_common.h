@@ -206,6 +206,7 @@ struct SplitLds {
     unsigned long long gptr[PRIVATE ? NB : 1];   // scan_part: byte address of (piece slot of stage index 0) per bin
     uint32_t total;
     uint32_t ovf_seen;          // some bin of this workgroup has run past its capacity (never cleared)
+    uint32_t ovf_lost;          // scan_part: records that found the overflow list full (kept here, not in a register of the hot loop)
 };
 
 
@@ -213,7 +214,7 @@ template <int THREADS, int PER_THREAD, class R>
 __device__ __forceinline__ void multisplit_init(SplitLds<THREADS, PER_THREAD, R> &L, int nbins)
 {
     for (int i = (int)threadIdx.x; i < L.N_BINS; i += THREADS) { L.cnt[i] = 0; L.cur[i] = 0; }
-    if (threadIdx.x == 0) L.ovf_seen = 0;
+    if (threadIdx.x == 0) { L.ovf_seen = 0; L.ovf_lost = 0; }
     __syncthreads();
 }
 

@@ -54,7 +54,7 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     asm volatile("v_mov_b32 %0, %1" : "=v"(b1_v) : "s"((uint32_t)b1));
     auto bin_of = [=](uint64_t h) -> uint32_t { return __builtin_amdgcn_ubfe((uint32_t)(h >> 32), bshift, b1_v); };
     const uint64_t canon_mask = canonical ? ~0ULL : 0ULL;
-    uint32_t n_records = 0, n_overflow = 0;
+    uint32_t n_records = 0;
     uint32_t n_all = 0;                                   // WINDOWED: valid windows inside or outside the window
     multisplit_init(L, nbins);
     Stamps st;
@@ -181,13 +181,16 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
         }
         R hs[PER_THREAD];
         uint32_t rk[PER_THREAD / 2];                     // ranks are < TILE <= 2^16: two per register
+        // which of the thread's windows became records: the plain k <= 32 scan has that in okbits (bit PER_THREAD - 1 - j) until
+        // the next tile is prepared, which is after the scatter; the other shapes decide per window and keep their own mask
+        constexpr bool KEEP_VALID = WIDE || WINDOWED;
         uint32_t valid = 0;
         // count phase of the first tile
 #pragma unroll
         for (int j = 0; j < PER_THREAD; j++) {
             uint32_t r = 0;
             if ((uint32_t)j < n_win && window(j, hs[j])) {
-                valid |= 1u << j;
+                if constexpr (KEEP_VALID) valid |= 1u << j;
                 r = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
             }
             rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
@@ -228,10 +231,11 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
             if (tid < nbins) L.cnt[tid] = 0;             // every scanning wave has read it
 #pragma unroll
             for (int j = 0; j < PER_THREAD; j++)
-                if ((valid >> j) & 1u) L.stage[L.off[bin_of(hs[j].h)] + ((rk[j / 2] >> (16 * (j & 1))) & 0xffffu)] = hs[j];
+                if (KEEP_VALID ? (valid >> j) & 1u : (okbits >> (PER_THREAD - 1 - j)) & 1u) L.stage[L.off[bin_of(hs[j].h)] + ((rk[j / 2] >> (16 * (j & 1))) & 0xffffu)] = hs[j];
             lds_barrier();                               // C: stage ready, cnt[] zero
             st.mark(2);
             const uint32_t total = L.total;
+            const uint32_t total_s = __builtin_amdgcn_readfirstlane(total);
             const bool checked = L.ovf_seen != 0;        // some piece may be full: bounds check + overflow list
             const bool has_next = tile + gridDim.x < n_tiles;
             if (has_next) {
@@ -240,33 +244,38 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
                 prep(tile + gridDim.x, w0, w1, w2, m0, m1);
             }
             valid = 0;
-            // copy-out of this tile, interleaved with the count phase of the next one
+            // copy-out of this tile, interleaved with the count phase of the next one.  Per record three LDS round trips (the
+            // staged record, the rank of the next tile's window, the bin's write pointer): the staged record is requested first
+            // and needed only after the window has been hashed.  The rank is packed outside the `checked` branch: both arms
+            // writing rk[] cost a copy of the whole array at their join, five moves per record.
 #pragma unroll
             for (int j = 0; j < PER_THREAD; j++) {
                 const uint32_t i = (uint32_t)j * THREADS + tid;
                 const bool mine = i < total;
-                R rec;
-                uint32_t bin = 0, idx = 0;
-                R *dst = nullptr;
-                if (mine) {
-                    rec = L.stage[i];
-                    bin = bin_of(rec.h);
-                    if (!checked) dst = (R *)(uintptr_t)L.gptr[bin] + i;
-                    else idx = i + L.delta[bin];         // 32-bit on purpose: delta is a wrapped difference
-                }
+                const R rec = L.stage[i];                  // (i < TILE: beyond `total` a stale record, never stored)
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t r;                                // the rank of a window that is no k-mer is never looked at: any value
+                asm volatile("" : "=v"(r));
                 if (has_next) {
-                    uint32_t r = 0;
                     if ((uint32_t)j < n_win && window(j, hs[j])) {
-                        valid |= 1u << j;
+                        if constexpr (KEEP_VALID) valid |= 1u << j;
                         r = atomicAdd(&L.cnt[bin_of(hs[j].h)], 1u);
                     }
-                    rk[j / 2] = (j & 1) ? rk[j / 2] | (r << 16) : r;
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t bin = bin_of(rec.h);
+                rk[j / 2] = (j & 1) ? __builtin_amdgcn_perm(r, rk[j / 2], 0x05040100u) : r;     // (low halves of both: one v_perm_b32)
+                __builtin_amdgcn_sched_barrier(0);
                 if (!checked) {
-                    if (mine) store_global(dst, rec);
+                    // (all but one of a tile's 16 strides lie wholly below `total`: decided on the scalar unit)
+                    if ((uint32_t)(j + 1) * THREADS <= total_s) store_global((R *)(uintptr_t)L.gptr[bin] + i, rec);
+                    else if (mine) store_global((R *)(uintptr_t)L.gptr[bin] + i, rec);
                 } else {
+                    const uint32_t idx = i + L.delta[bin];   // 32-bit on purpose: delta is a wrapped difference
                     if (mine && idx < capw) out[(uint64_t)bin * bin_stride + piece_base + idx] = rec;
-                    ovf_append(ovf, mine && idx >= capw, rec, n_overflow);
+                    uint32_t lost = 0;                       // (rare arm: tallied in LDS, so that no register crosses the arms' join)
+                    ovf_append(ovf, mine && idx >= capw, rec, lost);
+                    if (lost) atomicAdd(&L.ovf_lost, lost);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -285,9 +294,8 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     } else {
         if (tid == 0 && n_records) atomicAdd(&ctr->n_valid, (unsigned long long)n_records);
     }
-    n_overflow = (uint32_t)wave_sum(n_overflow);
-    if (lane_id() == 0 && n_overflow) {
-        atomicAdd(&ctr->n_overflow, (unsigned long long)n_overflow);
+    if (tid == 0 && L.ovf_lost) {                             // (multisplit_finish begins with a workgroup barrier)
+        atomicAdd(&ctr->n_overflow, (unsigned long long)L.ovf_lost);
         atomicMax(&ctr->fail_mark, 0xFFFFFFFFULL);           // records lost before any slab: everything is to be redone
     }
 }
