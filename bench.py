@@ -111,7 +111,7 @@ def roofline_of(stage_ms, stage_bytes, traffic_by_kernel, traffic_source, launch
     return out
 
 
-def committed_traffic(workload, reads, log2_bits, world):
+def committed_traffic(workload, reads, log2_bits, world, reads_per_step=None):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE, separate --pmc runs by tools/profile_round.sh), for the same workload only.  Static, not measured
     in this run: the JSON says so in roofline.traffic_source."""
@@ -123,8 +123,17 @@ def committed_traffic(workload, reads, log2_bits, world):
         entry = tj.get("workloads", {}).get(workload) or (tj if workload == "chr20" else None)
         if entry and entry.get("reads") == reads and entry.get("log2_bits") == log2_bits:
             # (a slab-wise stage launches its kernel once per slab: the stage's traffic is that of all its launches of a step)
-            return ({k: v.get("hbm_bytes_per_step", v.get("hbm_bytes_per_launch")) for k, v in entry.get("kernels", {}).items()},
-                    "profiles/traffic.json (static: committed rocprofv3 --pmc passes of this workload, not this run)")
+            per_step = {k: v.get("hbm_bytes_per_step", v.get("hbm_bytes_per_launch")) for k, v in entry.get("kernels", {}).items()}
+            src = "profiles/traffic.json (static: committed rocprofv3 --pmc passes of this workload, not this run)"
+            prof_rps = entry.get("reads_per_step")
+            if reads_per_step and prof_rps and abs(reads_per_step - prof_rps) > 0.005 * prof_rps:
+                # the box of this run fits another batch than the profiled one: everything a step moves follows the batch
+                # but the sweep of the set by the membership kernels (2^log2_bits / 8 bytes, read; the insert writes it back too)
+                sweep = {"seg_probe": (1 << log2_bits) / 8.0, "seg_exact_probe": (1 << log2_bits) / 8.0, "seg_insert": 2.0 * (1 << log2_bits) / 8.0}
+                ratio = reads_per_step / float(prof_rps)
+                per_step = {k: (max(v - sweep.get(k, 0.0), 0.0) * ratio + min(sweep.get(k, 0.0), v)) if v else v for k, v in per_step.items()}
+                src += "; scaled from the profiled batch of %d reads per step to this run's %d" % (prof_rps, reads_per_step)
+            return per_step, src
     except Exception:
         pass
     return None, None
@@ -768,7 +777,7 @@ def main():
                 stages[n] = ms / args.steps
                 b = stage_algorithmic_bytes(n, finish_stats, filter_bytes, rec_bytes, R, arb)
                 sb[n] = b / args.steps if b else None
-        traffic, tsrc = committed_traffic(args.workload, wl["reads"], args.log2_bits, world)
+        traffic, tsrc = committed_traffic(args.workload, wl["reads"], args.log2_bits, world, batch if wgs else None)
         slab_launches = {n: timed_slabs for n in ("repart", "seg_probe", "seg_exact_probe")} if wgs else None
         rl = roofline_of(stages, sb, traffic, tsrc, slab_launches)
         desc = {

@@ -123,7 +123,8 @@ def main():
                        "(MI355X_MICROARCH.md, HBM section). Every kernel is averaged over its last %d launches of full size = the child "
                        "steps (the parent inserts, which launch the partition kernels on other shapes, come first; the sampling "
                        "launch of the membership kernel on 64 segments is left out)." % LAST,
-               "workload": cfg.get("name"), "reads": cfg.get("reads_per_sample"), "log2_bits": cfg.get("filter_log2_bits"), "kernels": {}}
+               "workload": cfg.get("name"), "reads": cfg.get("reads_per_sample"), "reads_per_step": cfg.get("reads_per_step"),
+               "log2_bits": cfg.get("filter_log2_bits"), "kernels": {}}
     for name, c in per.items():
         if not c.get("FETCH_SIZE") or not c.get("WRITE_SIZE"):
             continue
