@@ -15,7 +15,7 @@ namespace dk {
 // records, <128, 512, 8 Kbit> (8 KB of LDS, many workgroups per CU) when a segment holds a few hundred.
 // PACKED (k <= 32 only): the pieces are units of an accumulator's packed store (6 bytes per record, dk_bucket_seg.h); the
 // extra list (the accumulator's overflow records) holds plain records.
-template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE, bool PACKED = false>
+template <int CNT_THREADS, int CNT_SLOTS, int CNT_BM_WORDS, bool WIDE, bool PACKED = false, int FAST = 0>
 __global__ void __launch_bounds__(CNT_THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T, uint64_t seed, uint32_t min_count,
                  uint64_t region_cap, uint64_t *__restrict__ out_kmer, uint64_t *__restrict__ out_hi,
@@ -71,7 +71,11 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     Stamps st;
     for (uint64_t seg_id = blockIdx.x; seg_id < n_seg; seg_id += gridDim.x) {
         const SegPieces<R> sp = seg_pieces(pl, seg_id);
-        const uint32_t n = sp.total();
+        // FAST (PACKED, one piece per unit; chosen by the host): 1 = no extra records anywhere, the unit is its packed blocks;
+        // 2 = the unit's index space is its packed blocks, whole, followed by its extra records -- [0, n_packed) records,
+        // [n_packed, np64) padding of the last block, [np64, n) extras
+        const uint32_t n_packed = sp.start[MAX_R], np64 = FAST == 2 ? (n_packed + 63u) & ~63u : n_packed;
+        const uint32_t n = FAST == 2 ? np64 + sp.n_extra : sp.total();
         if (n == 0) continue;
         const unsigned long long EMPTY = WIDE ? 0ULL : (unsigned long long)((seg_id + unit_base) ^ 1ULL) << (64 - T);
         const uint32_t n_chunks = (n + CNT_CHUNK - 1) / CNT_CHUNK;
@@ -93,14 +97,57 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 return sp.at(i);
             }
         };
+        // PACKED, one piece and no overflow records (an accumulator counted on its own GPU): record i of the unit sits in block
+        // i / 64 at lane i % 64, and a wave's 64 records of one register slot are exactly one block -- the block's address is
+        // wave-uniform, the lane's offset inside it the same for every slot: no per-record address arithmetic at all
+        // (FAST: chosen by the host when the list has one piece per unit and no extra records)
         auto load_chunk = [&](uint32_t c) {
+            if constexpr (PACKED && !WIDE && FAST) {
+                {
+                    const uint64_t unit = pl.n_segs ? seg_id : seg_id * pl.n_pieces;
+                    const char *ub = (const char *)pl.recs + unit * (uint64_t)pl.piece_cap * PACKED_REC_BYTES;
+                    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), lane = (uint32_t)tid & 63u;
+                    const uint32_t o32 = lane * 4u, o16 = (uint32_t)PACKED_BLOCK_RECS * 4u + lane * 2u;
+#pragma unroll
+                    for (int u = 0; u < CNT_RPT; u++) {
+                        const uint32_t blk = (c * CNT_CHUNK + (uint32_t)u * CNT_THREADS) / 64u + wave_s;      // wave-uniform
+                        if (blk * 64u >= n) continue;
+                        if (FAST == 1 || blk * 64u < np64) {   // (a block the unit has begun is allocated whole: its last lanes read padding)
+                            const char *b = ub + (uint64_t)blk * PACKED_BLOCK_BYTES;
+                            hv[u].h = prefix | ((uint64_t)*(const uint16_t *)(b + o16) << 32) | *(const uint32_t *)(b + o32);
+                        } else {                               // the unit's share of the overflow list (rare)
+                            const uint32_t x = blk * 64u + lane - np64;
+                            hv[u] = sp.extra[x < sp.n_extra ? x : 0];
+                        }
+                    }
+                    return;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < CNT_RPT; u++) {
                 const uint32_t i = c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid;
                 hv[u] = rec_at(i < n ? i : 0);
             }
         };
-        auto have = [&](uint32_t c, int u) -> bool { return c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid < n; };
+        auto have_at = [&](uint32_t c, int u) -> bool {
+            const uint32_t i = c * CNT_CHUNK + (uint32_t)u * CNT_THREADS + tid;
+            if constexpr (FAST == 2) return i < n_packed || (i >= np64 && i < n);
+            else return i < n;
+        };
+        // FAST, single chunk: which of the thread's slots hold a record, worked out once (the test runs in every pass)
+        uint32_t hmask = 0;
+        if constexpr (FAST == 2) {
+            if (single) {
+#pragma unroll
+                for (int u = 0; u < CNT_RPT; u++) hmask |= (have_at(0, u) ? 1u : 0u) << u;
+            }
+        }
+        auto have = [&](uint32_t c, int u) -> bool {
+            if constexpr (FAST == 2) {
+                if (single) return (hmask >> u) & 1u;
+            }
+            return have_at(c, u);
+        };
         // bitmap of >= 16 bits per record where the geometry has them (<= 6 % of the unique records collide and take the
         // table path), a power of two up to CNT_BM_WORDS
         uint32_t bm_words = 64;
@@ -115,6 +162,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         // computed once and kept, like the verdict of pass 2 (fbits) that passes 3 and 4 would otherwise re-derive
         constexpr bool KEEP_BITS = WIDE && CNT_RPT == 8;
         uint32_t bidx[KEEP_BITS ? CNT_RPT : 1];
+        constexpr bool KEEP_FLAGS = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no register to spare)
         uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
         for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
         if (single) load_chunk(0);
@@ -145,12 +193,12 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 else bit_of(hv[u], w, m);
                 const bool fl = (bm_b[w] & m) != 0;
                 if (fl) my_flagged++; else my_unique++;
-                if constexpr (KEEP_BITS) fbits |= (fl ? 1u : 0u) << u;
+                if constexpr (KEEP_FLAGS) fbits |= (fl ? 1u : 0u) << u;     // (used for a single chunk only)
             }
         }
         auto flagged = [&](int u, const R &rec) -> bool {
-            if constexpr (KEEP_BITS) {
-                if (single) return (fbits >> u) & 1u;
+            if constexpr (KEEP_FLAGS) {
+                if (single) return (fbits >> u) & 1u;   // the verdict of pass 2, kept: one bit per record instead of a hash + an LDS read
             }
             uint32_t w, m;
             bit_of(rec, w, m);

@@ -515,7 +515,13 @@ inline dk_status bucketed_count_stage(dk_engine *e, const PieceList<typename Rec
         /* (k <= 32 has the LDS for bitmaps of twice the words below the 1024-thread geometry: >= 16 bits per record up to the */ \
         /* geometry's capacity -- 6 % instead of 11 % of the unique records take the table path) */                               \
         constexpr int BMW = (WIDE || TH >= 1024) ? BM : 2 * BM;                                                                  \
-        if (packed && !WIDE)                                                                                                    \
+        if (packed && !WIDE && list.n_pieces == 1 && !list.extra)                                                              \
+            seg_count_kernel<TH, SLOTS, BMW, WIDE, !WIDE, WIDE ? 0 : 1><<<cgrid, TH, 0, e->stream>>>(                           \
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
+        else if (packed && !WIDE && list.n_pieces == 1)                                                                         \
+            seg_count_kernel<TH, SLOTS, BMW, WIDE, !WIDE, WIDE ? 0 : 2><<<cgrid, TH, 0, e->stream>>>(                           \
+                list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
+        else if (packed && !WIDE)                                                                                               \
             seg_count_kernel<TH, SLOTS, BMW, WIDE, !WIDE><<<cgrid, TH, 0, e->stream>>>(                                         \
                 list, n_units, Tc, e->cfg.seed, min_count, region_cap, res->d_lo, res->d_hi, res->d_cnt, e->d_ctr, unit_base);   \
         else                                                                                                                    \
