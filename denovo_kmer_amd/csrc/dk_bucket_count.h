@@ -154,14 +154,13 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         while (bm_words * 2 < n && bm_words < (uint32_t)CNT_BM_WORDS) bm_words <<= 1;
         const uint32_t bm_mask = bm_words * 32 - 1;
         auto bit_of = [=](const R &rec, uint32_t &w, uint32_t &m) {
-            const uint32_t b = (uint32_t)(fp_of(rec) >> 20) & bm_mask;
+            // (the record's hash, not its table fingerprint: equal k-mers have equal hashes, which is all the bitmaps need, and
+            // the k > 32 fingerprint costs an fmix64 -- now paid by the flagged records only)
+            const uint32_t b = (uint32_t)(rec.h >> 20) & bm_mask;
             w = b >> 5;
             m = 1u << (b & 31);
         };
-        // k > 32: the bitmap position of a record costs an fmix64; with the records in registers (single) it is
-        // computed once and kept, like the verdict of pass 2 (fbits) that passes 3 and 4 would otherwise re-derive
-        constexpr bool KEEP_BITS = WIDE && CNT_RPT == 8;
-        uint32_t bidx[KEEP_BITS ? CNT_RPT : 1];
+        // with the records in registers (single) the verdict of pass 2 is kept (fbits): passes 3 and 4 would otherwise re-derive it
         constexpr bool KEEP_FLAGS = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no register to spare)
         uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
         for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
@@ -176,7 +175,6 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 if (!have(c, u)) continue;
                 uint32_t w, m;
                 bit_of(hv[u], w, m);
-                if constexpr (KEEP_BITS) bidx[u] = (w << 5) | (uint32_t)__builtin_ctz(m);
                 if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
             }
         }
@@ -189,8 +187,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             for (int u = 0; u < CNT_RPT; u++) {
                 if (!have(c, u)) continue;
                 uint32_t w, m;
-                if (KEEP_BITS && single) { w = bidx[u] >> 5; m = 1u << (bidx[u] & 31); }
-                else bit_of(hv[u], w, m);
+                bit_of(hv[u], w, m);
                 const bool fl = (bm_b[w] & m) != 0;
                 if (fl) my_flagged++; else my_unique++;
                 if constexpr (KEEP_FLAGS) fbits |= (fl ? 1u : 0u) << u;     // (used for a single chunk only)
