@@ -742,6 +742,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"scan_positions", &dk_options::scan_positions, 0, 1},
         {"merge_undersize", &dk_options::merge_undersize, 0, 10},
         {"comm_staging_kb", &dk_options::comm_staging_kb, 0, 1 << 30},
+        {"l1_layout", &dk_options::l1_layout, 0, 1},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},

@@ -40,6 +40,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     __shared__ uint32_t wave_sums[CNT_THREADS / 64];
     __shared__ uint32_t total;
     __shared__ unsigned long long gbase;
+    constexpr bool TWO_POS = WIDE;                       // two bitmap positions per record (see bit2_of): pays where the table phase is dear
     constexpr bool GATHER = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no registers to spare)
     constexpr uint32_t WB = WIDE ? 32 : 64;              // per wave: flagged records gathered for one dense trip through the table
     __shared__ R wbuf[GATHER ? CNT_THREADS / 64 : 1][WB];
@@ -160,6 +161,17 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             w = b >> 5;
             m = 1u << (b & 31);
         };
+        // A second position from other hash bits: a record goes to the table only if BOTH of its positions were hit twice.
+        // All copies of a k-mer share both positions, so duplicates are still flagged, every one of them; a unique record is
+        // flagged only when two other records hit its two positions -- (2 n / bits)^2 instead of n / bits: 0.5 % instead of
+        // 3.4 % at 30 bits per record.  k > 32 only, where the table phase (fingerprints, a re-check pass: 58 % of the kernel's
+        // time at configs[4]) is what the flagged records cost: 19.5 -> 17.8 ms there; with 8-byte records the second
+        // position costs more than the smaller table saves (4.34 -> 4.48 ms per whole-genome step).
+        auto bit2_of = [=](const R &rec, uint32_t &w, uint32_t &m) {
+            const uint32_t b = (uint32_t)(rec.h >> 2) & bm_mask;
+            w = b >> 5;
+            m = 1u << (b & 31);
+        };
         // with the records in registers (single) the verdict of pass 2 is kept (fbits): passes 3 and 4 would otherwise re-derive it
         constexpr bool KEEP_FLAGS = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no register to spare)
         uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
@@ -176,6 +188,10 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 uint32_t w, m;
                 bit_of(hv[u], w, m);
                 if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
+                if constexpr (TWO_POS) {
+                    bit2_of(hv[u], w, m);
+                    if (atomicOr(&bm_a[w], m) & m) atomicOr(&bm_b[w], m);
+                }
             }
         }
         lds_barrier();
@@ -188,7 +204,11 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 if (!have(c, u)) continue;
                 uint32_t w, m;
                 bit_of(hv[u], w, m);
-                const bool fl = (bm_b[w] & m) != 0;
+                bool fl = (bm_b[w] & m) != 0;
+                if constexpr (TWO_POS) {
+                    bit2_of(hv[u], w, m);
+                    fl = fl && (bm_b[w] & m) != 0;
+                }
                 if (fl) my_flagged++; else my_unique++;
                 if constexpr (KEEP_FLAGS) fbits |= (fl ? 1u : 0u) << u;     // (used for a single chunk only)
             }
@@ -199,7 +219,12 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
             }
             uint32_t w, m;
             bit_of(rec, w, m);
-            return (bm_b[w] & m) != 0;
+            bool fl = (bm_b[w] & m) != 0;
+            if constexpr (TWO_POS) {
+                bit2_of(rec, w, m);
+                fl = fl && (bm_b[w] & m) != 0;
+            }
+            return fl;
         };
         const uint32_t emit_unique = min_count <= 1 ? 1u : 0u;
         const uint32_t wave_unique = wave_total(my_unique);          // uniform per wave

@@ -227,13 +227,30 @@ inline void free_bufs(dk_engine *e, BucketBufs<R> &B)
 }
 
 // level 2 of one slab (p.slabs == 1: of the whole batch): the level-1 pieces of the slab's bins -> the regions of these
+// Where the level-1 pieces lie in B.a: piece w of bin b starts at record b * bin_stride + w * piece_stride.
+//   bin-major (default): a bin's G pieces side by side, 128 bytes between bins
+//   workgroup-major (option "l1_layout" = 1): a scan_part workgroup's 2^b1 pieces side by side, 128 bytes between workgroups --
+//   its 2^b1 write frontiers then lie within 2^b1 * capw records (180 MB at configs[2]: ~90 pages of 2 MiB) instead of one per
+//   bin across the whole 46-GB buffer.  Measured equal (child step: scan_part 20.8 both, repart 20.4 vs 20.3; parent batch:
+//   scan_part 50.1 vs 51.8, repart 51.5 vs 51.0): page reach is not what holds the scan's stores.
+struct Level1Layout {
+    uint64_t bin_stride, piece_stride, total;
+};
+template <class R>
+inline Level1Layout level1_layout(const dk_engine *e, const BucketPlan &p)
+{
+    const uint64_t skew = 128u / (uint32_t)sizeof(R);
+    if (e->opt.l1_layout != 1) return Level1Layout{(uint64_t)p.G * p.capw + skew, p.capw, (uint64_t)p.p1 * ((uint64_t)p.G * p.capw + skew)};
+    return Level1Layout{p.capw, (uint64_t)p.p1 * p.capw + skew, (uint64_t)p.G * ((uint64_t)p.p1 * p.capw + skew)};
+}
+
 // bins in B.b (two levels), or -> 2^(b1+b2) coarse regions (three levels; never slab-wise)
 template <bool WIDE>
 inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename RecOf<WIDE>::type> &B, int wbits, uint32_t slab)
 {
     using R = typename RecOf<WIDE>::type;
     const OvfList<R> ovf{B.ovf, &e->d_ctr->n_ovf, B.ovf_cap};
-    const uint32_t l1_skew = 128u / (uint32_t)sizeof(R);
+    const Level1Layout L1 = level1_layout<R>(e, p);
     const uint32_t bin0 = slab * p.slab_bins;
     const int affine = !e->opt.repart_plain && p.slab_bins % 8 == 0;
 #define DK_REPART_LAUNCH(TH, PT, W)                                                                       \
@@ -241,7 +258,7 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
         const uint32_t tpp = (p.capw + TH * PT - 1) / (TH * PT);                                           \
         repart_kernel<TH, PT, W, R><<<repart_grid(p.G * tpp, p.slab_bins), TH, 0, e->stream>>>(            \
             B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
-            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, L1.bin_stride, L1.piece_stride, bin0, slab);                      \
     } while (0)
     // The pieces of a bin read as one array (full tiles) where tiles cut piece by piece would be poorly filled: the
     // concatenating kernel costs ~6 % more per tile (prefix sum of the piece sizes, bisection), so it is taken when the
@@ -258,7 +275,7 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
         const uint32_t tpb = (uint32_t)(((uint64_t)p.G * p.capw + TH * PT - 1) / (TH * PT));               \
         repart_kernel<TH, PT, W, R, false, true><<<repart_grid(tpb, p.slab_bins), TH, 0, e->stream>>>(     \
             B.a, B.cnt1, p.G, p.capw, tpb, wbits + p.b1, p.b2, p.b3 ? p.capA : p.cap2, B.b,                 \
-            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);                      \
+            p.b3 ? B.cursorA : B.cursor2, ovf, e->d_ctr, affine, L1.bin_stride, L1.piece_stride, bin0, slab);                      \
     } while (0)
     if (concat && !p.packed2 && !(e->opt.repart_variant == 1 && !WIDE)) {
         if constexpr (WIDE) DK_REPART_CONCAT(512, 8, 8);
@@ -267,7 +284,7 @@ inline void launch_repart(dk_engine *e, const BucketPlan &p, BucketBufs<typename
     else if (p.packed2) {
         const uint32_t tpp = (p.capw + 1024 * 8 - 1) / (1024 * 8);
         repart_kernel<1024, 8, 8, R, true><<<repart_grid(p.G * tpp, p.slab_bins), 1024, 0, e->stream>>>(
-            B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.cap2, B.b, B.cursor2, ovf, e->d_ctr, affine, l1_skew, bin0, slab);
+            B.a, B.cnt1, p.G, p.capw, tpp, wbits + p.b1, p.b2, p.cap2, B.b, B.cursor2, ovf, e->d_ctr, affine, L1.bin_stride, L1.piece_stride, bin0, slab);
     } else if (e->opt.repart_variant == 1) DK_REPART_LAUNCH(1024, 16, 4);
     else DK_REPART_LAUNCH(1024, 8, 8);
 #undef DK_REPART_LAUNCH
@@ -290,8 +307,8 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
     // 128 bytes between the pieces of consecutive level-1 bins: a workgroup of scan_part writes to 2^b1 frontiers that are
     // G * capw records apart, always a multiple of 4 KiB, so all of them sat on the same few HBM channels at any moment
     // (configs[1]: scan_part 4.75 -> 4.35 ms on one box, no difference on others)
-    const uint32_t l1_skew = 128u / (uint32_t)sizeof(R);
-    const uint64_t lvl1_recs = (uint64_t)p.p1 * (p.G * (uint64_t)p.capw + l1_skew);
+    const Level1Layout L1 = level1_layout<R>(e, p);
+    const uint64_t lvl1_recs = L1.total;
     const uint64_t n_coarse = p.b3 ? 1ULL << (p.b1 + p.b2) : 0;
     const uint64_t coarse_recs = n_coarse * p.capA;
     // two levels: a = level-1 pieces (then the absent lists), b = segments.  three: a = level 1, then segments; b = coarse (then absent lists)
@@ -330,7 +347,7 @@ inline dk_status bucketed_partition(dk_engine *e, const dk_reads *r, const Bucke
 #define DK_SCAN_LAUNCH(TH, PT, W, WIN)                                                                                    \
     scan_part_kernel<TH, PT, W, WIDE, WIN><<<p.G, TH, 0, e->stream>>>(sv, (int)e->cfg.k, (int)e->cfg.canonical,           \
                                                                       e->cfg.seed, p.b1, p.capw, B.a, B.cnt1, n_tiles,    \
-                                                                      ovf, e->d_ctr, wbits, widx, l1_skew,                \
+                                                                      ovf, e->d_ctr, wbits, widx, L1.bin_stride, L1.piece_stride, \
                                                                       (PT == 16 ? wmv : WindowMajor{0, 0, 0, 0, nullptr}))
     // level 3: every coarse region is one "piece" (G = 1) of the same kernel, split by b3 more bits
 #define DK_REPART3_LAUNCH(TH, PT, W)                                                                      \

@@ -21,8 +21,8 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES, class R, bool PK = false, 
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint32_t G, uint32_t capw,
               uint32_t tiles_per_piece, int b1, int b2, uint32_t cap2, R *__restrict__ out,
-              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0, uint32_t bin_skew = 0,
-              uint32_t bin0 = 0, uint32_t slab = 0)
+              uint32_t *__restrict__ cursor2, OvfList<R> ovf, Counters *ctr, int xcd_affine = 0, uint64_t bin_stride = 0,
+              uint64_t piece_stride = 0, uint32_t bin0 = 0, uint32_t slab = 0)
 {
     // bin0 / slab: slab-wise partition (bucketed_partition) -- this launch covers the level-1 bins from bin0 on, and `out`
     // holds the regions of these bins only (region (bin0 << b2) first); cursor2 is indexed by the region's global number
@@ -63,7 +63,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         const uint64_t piece = (uint64_t)b * G + w;
         n = cnt1[piece];
         if (n > capw) n = capw;
-        src = in + piece * capw + (uint64_t)b * bin_skew;
+        src = bin_stride ? in + (uint64_t)b * bin_stride + (uint64_t)w * piece_stride : in + piece * capw;     // (level 3: plain pieces)
     }
     if (t0 >= n) return;
     const int nbins = 1 << b2;
@@ -76,7 +76,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
         // piece of the thread's first record by bisection; the later ones lie THREADS records further each: at most one
         // step on per record in the usual case (pieces of thousands of records), bisection again otherwise.  Positions
         // beyond the bin's end read its last record (ignored below), which keeps the walk monotonic.
-        const R *bin_base = in + (uint64_t)b * G * capw + (uint64_t)b * bin_skew;
+        const R *bin_base = in + (uint64_t)b * bin_stride;
         auto bisect = [&](uint32_t r) -> uint32_t {
             uint32_t lo = 0, hi = G;
             while (hi - lo > 1) {
@@ -96,7 +96,7 @@ repart_kernel(const R *__restrict__ in, const uint32_t *__restrict__ cnt1, uint3
                 w++;
                 if (pstart[w + 1] <= r) w = bisect(r);
             }
-            hs[j] = bin_base[(uint64_t)w * capw + (r - pstart[w])];
+            hs[j] = bin_base[(uint64_t)w * piece_stride + (r - pstart[w])];
         }
     } else {
 #pragma unroll

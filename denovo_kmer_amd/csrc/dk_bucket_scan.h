@@ -36,8 +36,8 @@ template <int THREADS, int PER_THREAD, int MIN_WAVES, bool WIDE, bool WINDOWED>
 __global__ void __launch_bounds__(THREADS, MIN_WAVES)
 scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint32_t capw,
                  typename RecOf<WIDE>::type *__restrict__ out, uint32_t *__restrict__ cnt1, uint32_t n_tiles,
-                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx, uint32_t bin_skew,
-                 WindowMajor wmv)
+                 OvfList<typename RecOf<WIDE>::type> ovf, Counters *ctr, int wbits, uint32_t widx, uint64_t bin_stride,
+                 uint64_t piece_stride, WindowMajor wmv)
 {
     using R = typename RecOf<WIDE>::type;
     constexpr int TILE = THREADS * PER_THREAD;
@@ -91,9 +91,10 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     const int sk = (WIDE ? 128 : 64) - 2 * k;            // right-alignment shift of a window
     const uint64_t kmask_shift = 64 - k;
     const uint64_t G = gridDim.x, w = blockIdx.x;
-    // bin_skew: records between the end of one bin's pieces and the start of the next bin's (keeps the 2^b1 write frontiers
-    // of a workgroup, G * capw records apart, off a common multiple of 4 KiB)
-    const uint64_t piece_base = w * capw, bin_stride = G * capw + bin_skew;
+    // Piece w of bin b starts at record b * bin_stride + w * piece_stride of `out` (Level1Layout, dk_bucket_host.h):
+    // bin-major (a bin's pieces side by side) or workgroup-major (a workgroup's pieces side by side: its 2^b1 write
+    // frontiers then lie within 2^b1 * capw records instead of being spread over the whole buffer -- far fewer pages)
+    const uint64_t piece_base = w * piece_stride;
 
     // the tile being hashed: stream left-aligned at p0 -- bases in (v0, v1[, v2]), flags in (mh, ml)
     uint64_t p0 = 0, v0 = 0, v1 = 0, v2 = 0, mh = 0, ml = 0, rch = 0, rcl = 0;

@@ -24,6 +24,7 @@ def _case(seed):
             "repart_pieces": int(rng.choice([0, 1, 2])), "accum_min_u": int(rng.choice([0, 4, 8, 10])),
             "accum_plain": int(rng.integers(0, 2)), "scan_positions": int(rng.integers(0, 2)),
             "scan_variant": int(rng.choice([0, 0, 2, 6])), "l2_packed": int(rng.integers(0, 2))}
+    opts["l1_layout"] = seed % 2               # (added after the draws above: the cases of earlier rounds keep their inputs)
     return rng, k, lo, hi, log2_bits, int(rng.integers(1, 9)), int(rng.choice([1, 1, 2, 4])), opts
 
 

@@ -734,6 +734,9 @@ def test_repart_over_pieces_and_over_their_concatenation_agree(repart_pieces):
     _forced_geometry_trio({"repart_pieces": repart_pieces}, ["scan_part", "repart"])
     _forced_geometry_trio({"repart_pieces": repart_pieces, "force_l3": 1}, ["scan_part", "repart", "repart3"])
     _forced_geometry_trio({"repart_pieces": repart_pieces, "scan_variant": 5}, ["scan_part", "repart"])
+    # the level-1 pieces workgroup-major instead of bin-major (option "l1_layout"): the same records at other addresses
+    _forced_geometry_trio({"repart_pieces": repart_pieces, "l1_layout": 1}, ["scan_part", "repart"])
+    _forced_geometry_trio({"repart_pieces": repart_pieces, "l1_layout": 1, "scan_variant": 5}, ["scan_part", "repart"])
 
 
 def test_forced_scan_shape_with_fewer_threads_than_bins():
