@@ -39,6 +39,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
     __shared__ uint32_t bm_a[CNT_BM_WORDS], bm_b[CNT_BM_WORDS];
     __shared__ uint32_t wave_sums[CNT_THREADS / 64];
     __shared__ uint32_t total;
+    __shared__ uint32_t fcount;                          // few-flagged path: records gathered so far
     __shared__ unsigned long long gbase;
     constexpr bool TWO_POS = WIDE;                       // two bitmap positions per record (see bit2_of): pays where the table phase is dear
     constexpr bool GATHER = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no registers to spare)
@@ -176,6 +177,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         constexpr bool KEEP_FLAGS = !(WIDE && CNT_THREADS == 1024);     // (that geometry has no register to spare)
         uint32_t fbits = 0;                                // bit u: record u of this thread may have a twin (single only)
         for (uint32_t i = tid; i < bm_words; i += CNT_THREADS) { bm_a[i] = 0; bm_b[i] = 0; }
+        if (tid == 0) fcount = 0;
         if (single) load_chunk(0);
         lds_barrier();
         st.mark(0);                                   // (DK_STAMPS) bitmaps cleared, records in registers
@@ -273,7 +275,57 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
         // round.  The number of rounds starts from a guess (8 copies per key) and a round whose keys
         // do not fit is split in four and redone -- nothing of it has been emitted yet -- so a segment
         // holding a million copies of one k-mer costs one round, not a thousand.
-        if (n_flagged) {
+        // Few flagged records (at most 64, all in registers): no table.  Every wave appends its flagged records to one LDS list;
+        // wave 0 then compares each with all of them -- the full key, so nothing needs a re-check -- counts its copies, and the
+        // first copy of every k-mer reports it.  One barrier instead of the table's six, no clearing, no second walk; the
+        // other waves go on to the next unit (the list is not written again before wave 0 has passed two more barriers).
+        constexpr bool FEW = GATHER;
+        bool few_done = false;
+        if (FEW && n_flagged && n_flagged <= 64 && single) {
+            R *const flist = &wbuf[0][0];                  // (CNT_THREADS / 64 * WB >= 64 entries)
+#pragma unroll
+            for (int u = 0; u < CNT_RPT; u++) {
+                const bool want = have(0, u) && flagged(u, hv[u]);
+                if (__ballot(want) == 0) continue;
+                if (want) flist[atomicAdd(&fcount, 1u)] = hv[u];
+            }
+            lds_barrier();
+            if (wave == 0) {
+                const uint32_t lane = (uint32_t)lane_id(), nf = n_flagged;
+                const R mine = flist[lane < nf ? lane : 0];
+                uint32_t copies = 0;
+                bool first = lane < nf;
+                for (uint32_t j = 0; j < nf; j++) {
+                    const R o = flist[j];                  // (one address for all lanes: a broadcast read)
+                    bool eq = o.h == mine.h;
+                    if constexpr (WIDE) eq = eq && rec_hi(o) == rec_hi(mine);
+                    copies += eq ? 1u : 0u;
+                    if (eq && j < lane) first = false;
+                }
+                const bool keep = first && copies >= min_count;
+                const uint64_t kb = __ballot(keep);
+                const uint32_t n_first = (uint32_t)__popcll(__ballot(first));     // (by every lane: not inside the conditional below)
+                n_distinct += lane == 0 ? n_first : 0u;
+                if (kb) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(fill, (unsigned long long)__popcll(kb));
+                    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+                    if (keep) {
+                        const uint64_t o = base + (uint64_t)popc_below(kb);
+                        if (o < region_cap) {
+                            out_kmer[region_base + o] = rec_lo(mine, seed);
+                            if constexpr (WIDE) out_hi[region_base + o] = rec_hi(mine);
+                            out_cnt[region_base + o] = copies;
+                        } else {
+                            n_fail++;
+                        }
+                    }
+                }
+            }
+            few_done = true;
+        }
+        if (n_flagged && !few_done) {
             uint32_t slots = 256;
             while (slots < 2 * n_flagged && slots < (uint32_t)CNT_SLOTS) slots <<= 1;
             const uint32_t slot_mask = slots - 1;
@@ -413,7 +465,7 @@ seg_count_kernel(PieceList<typename RecOf<WIDE>::type> pl, uint64_t n_seg, int T
                 r++;
             }
         }
-        lds_barrier();
+        if (!few_done) lds_barrier();                 // (the table and its counters are cleared by the next unit)
         st.mark(3);                                   // flagged records counted and emitted
     }
     st.flush(ctr, 4);
