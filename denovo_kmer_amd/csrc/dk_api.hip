@@ -708,6 +708,14 @@ dk_status dk_engine_get_info(const dk_engine *e, const char *name, int64_t *valu
     };
     for (const auto &i : info)
         if (strcmp(name, i.name) == 0) { *value = i.v; return DK_OK; }
+#ifdef DK_DEBUG_INFO
+    if (strncmp(name, "dbg", 3) == 0 && name[3] >= '0' && name[3] <= '7') {       // diagnostic builds: Counters::dbg[n] as the device holds it
+        Counters c;
+        (void)hipMemcpy(&c, e->d_ctr, sizeof c, hipMemcpyDeviceToHost);
+        *value = (int64_t)c.dbg[name[3] - '0'];
+        return DK_OK;
+    }
+#endif
     return DK_ERR_INVALID_ARG;
 }
 
@@ -743,6 +751,7 @@ dk_status dk_engine_set_option(dk_engine *e, const char *name, int64_t value)
         {"merge_undersize", &dk_options::merge_undersize, 0, 10},
         {"comm_staging_kb", &dk_options::comm_staging_kb, 0, 1 << 30},
         {"l1_layout", &dk_options::l1_layout, 0, 1},
+        {"l1_skew", &dk_options::l1_skew, 0, 1 << 24},
         {"merge_pass_bits", &dk_options::merge_pass_bits, 0, 8},
         {"sink_plain", &dk_options::sink_plain, 0, 1},
         {"accum_unit_cap", &dk_options::accum_unit_cap, 0, 1 << 20},

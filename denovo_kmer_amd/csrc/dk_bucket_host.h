@@ -239,7 +239,7 @@ struct Level1Layout {
 template <class R>
 inline Level1Layout level1_layout(const dk_engine *e, const BucketPlan &p)
 {
-    const uint64_t skew = 128u / (uint32_t)sizeof(R);
+    const uint64_t skew = (uint64_t)(e->opt.l1_skew > 0 ? e->opt.l1_skew : 128) / (uint32_t)sizeof(R);      // (option "l1_skew": bytes, a multiple of 16)
     if (e->opt.l1_layout != 1) return Level1Layout{(uint64_t)p.G * p.capw + skew, p.capw, (uint64_t)p.p1 * ((uint64_t)p.G * p.capw + skew)};
     return Level1Layout{p.capw, (uint64_t)p.p1 * p.capw + skew, (uint64_t)p.G * ((uint64_t)p.p1 * p.capw + skew)};
 }

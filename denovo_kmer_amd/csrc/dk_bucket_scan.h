@@ -58,6 +58,13 @@ scan_part_kernel(StreamView s, int k, int canonical, uint64_t seed, int b1, uint
     uint32_t n_all = 0;                                   // WINDOWED: valid windows inside or outside the window
     multisplit_init(L, nbins);
     Stamps st;
+#ifdef DK_DEBUG_INFO
+    if (blockIdx.x == 0 && threadIdx.x == 0) {           // where the kernel's code was loaded (instruction-cache alignment studies)
+        unsigned long long pc;
+        asm volatile("s_getpc_b64 %0" : "=s"(pc));
+        ctr->dbg[7] = pc;
+    }
+#endif
 
     const uint64_t last_b = s.n_bwords - 1, last_m = s.n_mwords - 1;
     // window-major (k <= 32 only; decided once per launch from the batch's device flag): tiles count thread slots, not positions

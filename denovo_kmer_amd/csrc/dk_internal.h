@@ -60,6 +60,7 @@ struct dk_options {
     int merge_pass_bits = 0;      // dk_result_merge: at least 2^n hash-range passes
     int accum_unit_cap = 0;       // dk_accum_create: records per counting unit, when at least what the capacity needs (test hook)
     int sink_plain = 0;           // dk_probe: never sink the absent records into finer counting units (test hook)
+    int l1_skew = 0;              // bytes between the level-1 pieces of consecutive bins (0 = 128; A/B runs)
     int l1_layout = 0;            // level-1 pieces: 0 = bin-major, 1 = workgroup-major (measured equal; A/B runs, tests)
     int comm_staging_kb = 0;      // dk_comm_init: size of the staging buffer in KiB (0 = 1 GiB; tests: many pieces on small sets)
     int merge_undersize = 0;      // dk_result_merge: start with pass tables 2^n times too small (test hook: the redo path)

@@ -143,7 +143,8 @@ dk_status   dk_engine_config(const dk_engine *e, dk_config *out);
  *   of its pieces; 0 = automatic), "scan_positions" 0..1 (1: the scan never deals windows instead of positions to its threads
  *   for batches of one read length), "kmers_plain" 0..1 (1: ordinary instead of non-temporal stores in dk_reads_kmers),
  *   "comm_staging_kb" (size of the staging buffer dk_comm_init takes, KiB; 0 = 1 GiB; at least 64 KiB per peer),
- *   "l1_layout" 0..1 (level-1 pieces bin-major / workgroup-major: measured equal, kept for A/B runs) */
+ *   "l1_layout" 0..1 (level-1 pieces bin-major / workgroup-major: measured equal, kept for A/B runs), "l1_skew" (bytes
+ *   between the level-1 pieces of consecutive bins, a multiple of 16; 0 = 128) */
 dk_status   dk_engine_set_option(dk_engine *e, const char *name, int64_t value);
 /* What the engine did / holds, by name: "plan_levels", "plan_b1", "plan_b2", "plan_b3", "plan_sbits", "plan_slabs",
  * "plan_scan_variant", "plan_segment_bits" (the partition plan of the last bucketed operation), "pool_bytes_in_use",
