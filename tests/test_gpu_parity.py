@@ -737,6 +737,9 @@ def test_repart_over_pieces_and_over_their_concatenation_agree(repart_pieces):
     # the level-1 pieces workgroup-major instead of bin-major (option "l1_layout"): the same records at other addresses
     _forced_geometry_trio({"repart_pieces": repart_pieces, "l1_layout": 1}, ["scan_part", "repart"])
     _forced_geometry_trio({"repart_pieces": repart_pieces, "l1_layout": 1, "scan_variant": 5}, ["scan_part", "repart"])
+    # other distances between the pieces of consecutive bins (option "l1_skew", bytes)
+    _forced_geometry_trio({"repart_pieces": repart_pieces, "l1_skew": 4224}, ["scan_part", "repart"])
+    _forced_geometry_trio({"repart_pieces": repart_pieces, "l1_skew": 16, "l1_layout": 1}, ["scan_part", "repart"])
 
 
 def test_forced_scan_shape_with_fewer_threads_than_bins():
